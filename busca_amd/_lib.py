@@ -1,0 +1,99 @@
+"""ctypes binding of libbusca_hip.so (include/busca_hip.h).  No fallback: if the library is missing the
+import of any compute path raises - the product never computes on the CPU."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbusca_hip.so")
+
+ACT_RELU, ACT_GELU = 0, 1
+PREC_F32, PREC_F16 = 0, 1
+PAIR_CENTER, PAIR_CENTER_WEIGHTED, PAIR_IOU, PAIR_IOU_COST = 0, 1, 2, 3
+
+
+class DTCfg(C.Structure):
+    _fields_ = [("d", C.c_int32), ("ff", C.c_int32), ("nhead", C.c_int32), ("nlayers", C.c_int32),
+                ("E", C.c_int32), ("activation", C.c_int32), ("fake_bbox_f64", C.c_int32),
+                ("precision", C.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/busca_hip.h one to one
+_vp, _i32, _sz = C.c_void_p, C.c_int32, C.c_size_t
+SIGNATURES = {
+    "busca_version": (C.c_int, []),
+    "busca_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "busca_ctx_destroy": (None, [_vp]),
+    "busca_last_error": (C.c_char_p, [_vp]),
+    "busca_dt_blob_floats": (_sz, [C.POINTER(DTCfg)]),
+    "busca_dt_load_weights": (C.c_int, [_vp, C.POINTER(DTCfg), _vp, _sz, _vp, _vp, _vp, _i32]),
+    "busca_dt_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "busca_dt_bucket_ids": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "busca_timing_enable": (C.c_int, [_vp, _i32]),
+    "busca_timing_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i32]),
+    "busca_pairwise": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "busca_topk_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "busca_crop_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "busca_reid_blob_floats": (_sz, []),
+    "busca_reid_load_weights": (C.c_int, [_vp, _vp, _sz]),
+    "busca_reid_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "busca_reid_workspace_bytes": (_sz, [_i32]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and type every entry point.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing - run `python -m busca_amd.build` (hipcc, gfx950). "
+                              "busca_amd has no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class BuscaError(RuntimeError):
+    pass
+
+
+class Context:
+    """One busca_ctx per process/GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.busca_ctx_create(int(device), C.byref(h))
+        if rc != 0 or not h.value:
+            raise BuscaError("busca_ctx_create(device=%d) failed with %d (is a GPU visible?)" % (device, rc))
+        self.h = h
+        self.device = int(device)
+
+    def check(self, rc):
+        if rc != 0:
+            raise BuscaError("libbusca_hip error %d: %s" % (rc, self.lib.busca_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.busca_ctx_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data

@@ -1,0 +1,68 @@
+"""Host handle of the fused Decision-Transformer kernel (busca_dt_* in include/busca_hip.h).
+
+Inputs/outputs are torch tensors on the GPU; torch only provides device memory and the stream."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, weights
+
+_PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16}
+_ACT = {"relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU}
+
+
+class DecisionTransformerHIP:
+    def __init__(self, ctx, state_dict, activation="relu", fake_bbox_f64=True, precision="f32"):
+        self.ctx = ctx
+        d, ff, nl, E = weights.dt_dims(state_dict)
+        self.d, self.ff, self.nlayers, self.E, self.nhead = d, ff, nl, E, 4
+        self.precision = precision
+        self.cfg = _lib.DTCfg(d, ff, 4, nl, E, _ACT[activation], 1 if fake_bbox_f64 else 0, _PREC[precision])
+        blob = weights.dt_blob(state_dict, nl)
+        want = ctx.lib.busca_dt_blob_floats(C.byref(self.cfg))
+        if want == 0:
+            raise _lib.BuscaError("unsupported Decision-Transformer shape d=%d ff=%d layers=%d E=%d" % (d, ff, nl, E))
+        assert blob.size == want, (blob.size, want)
+        lxy, lsz, lt, c = weights.encoding_luts(d)
+        ctx.check(ctx.lib.busca_dt_load_weights(ctx.h, C.byref(self.cfg), blob.ctypes.data, blob.size,
+                                                lxy.ctypes.data, lsz.ctypes.data, lt.ctypes.data, c))
+
+    @staticmethod
+    def _f32(t, dev):
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(np.asarray(t))
+        return t.to(device=dev, dtype=torch.float32).contiguous()
+
+    def forward(self, mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=False, want_att=False, stream=None):
+        """-> dict(logits[B,P+2], probs[B,P+2], argmax[B] int32, hidden?[B,T,d], att?[nl,B,4,T,T])."""
+        dev = torch.device("cuda", self.ctx.device)
+        mem_feat, can_feat = self._f32(mem_feat, dev), self._f32(can_feat, dev)
+        mem_ltrb, can_ltrb = self._f32(mem_ltrb, dev), self._f32(can_ltrb, dev)
+        B, L, E = mem_feat.shape
+        P = can_feat.shape[1]
+        assert E == self.E and can_feat.shape == (B, P, E) and mem_ltrb.shape == (B, L, 4) and can_ltrb.shape == (B, P, 4)
+        T = L + 2 * (P + 2)
+        out = dict(logits=torch.empty(B, P + 2, device=dev), probs=torch.empty(B, P + 2, device=dev),
+                   argmax=torch.empty(B, dtype=torch.int32, device=dev))
+        if want_hidden:
+            out["hidden"] = torch.empty(B, T, self.d, device=dev)
+        if want_att:
+            out["att"] = torch.empty(self.nlayers, B, 4, T, T, device=dev)
+        s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        self.ctx.check(self.ctx.lib.busca_dt_forward(
+            self.ctx.h, mem_feat.data_ptr(), can_feat.data_ptr(), mem_ltrb.data_ptr(), can_ltrb.data_ptr(), B, L, P,
+            out["logits"].data_ptr(), out["probs"].data_ptr(), out["argmax"].data_ptr(),
+            _lib.ptr(out.get("hidden")), _lib.ptr(out.get("att")), s))
+        return out
+
+    def bucket_ids(self, mem_ltrb, can_ltrb):
+        dev = torch.device("cuda", self.ctx.device)
+        mem_ltrb, can_ltrb = self._f32(mem_ltrb, dev), self._f32(can_ltrb, dev)
+        B, L, _ = mem_ltrb.shape
+        P = can_ltrb.shape[1]
+        ids = torch.empty(B, L + 2 * (P + 2), 3, dtype=torch.int32, device=dev)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        self.ctx.check(self.ctx.lib.busca_dt_bucket_ids(self.ctx.h, mem_ltrb.data_ptr(), can_ltrb.data_ptr(), B, L, P,
+                                                       ids.data_ptr(), s))
+        return ids

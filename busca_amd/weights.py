@@ -1,0 +1,58 @@
+"""Reference state_dict  <->  flat float32 weight blobs for libbusca_hip.so.
+
+Key names are the reference's (busca/network.py:45-94); the order of the blob is
+the one documented in include/busca_hip.h."""
+import numpy as np
+
+
+def _np(v):
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+
+
+def dt_blob_keys(nlayers):
+    keys = ["encoder.weight", "encoder.bias", "sep_token", "non_token", "bad_token"]
+    for i in range(nlayers):
+        p = "transformer_encoder.layers.%d." % i
+        keys += [p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", p + "self_attn.out_proj.weight",
+                 p + "self_attn.out_proj.bias", p + "linear1.weight", p + "linear1.bias", p + "linear2.weight",
+                 p + "linear2.bias", p + "norm1.weight", p + "norm1.bias", p + "norm2.weight", p + "norm2.bias"]
+    keys += ["decoder.0.weight", "decoder.0.bias", "decoder.1.weight", "decoder.1.bias"]
+    return keys
+
+
+def dt_blob(state_dict, nlayers):
+    """Concatenate the Decision-Transformer tensors of a reference state_dict into the C-ABI blob."""
+    missing = [k for k in dt_blob_keys(nlayers) if k not in state_dict]
+    if missing:
+        raise KeyError("state_dict lacks %s" % missing[:4])
+    return np.concatenate([_np(state_dict[k]).ravel() for k in dt_blob_keys(nlayers)])
+
+
+def dt_dims(state_dict):
+    """(d, ff, nlayers, E) from tensor shapes."""
+    d, E = _np(state_dict["encoder.weight"]).shape
+    ff = _np(state_dict["transformer_encoder.layers.0.linear1.weight"]).shape[0]
+    nl = 0
+    while "transformer_encoder.layers.%d.linear1.weight" % nl in state_dict:
+        nl += 1
+    return d, ff, nl, E
+
+
+def encoding_luts(d):
+    """The three per-axis fp16 LUTs that the reference's 211x211x61xd table (busca/encodings.py:23-32)
+    factors into: interleaved sin/cos of pos / 10000^(2j/c), c = 2*ceil(d/6), float32 torch CPU math
+    (the ops the third-party positional_encodings 6.0.3 module runs) then fp16.  Returns uint16 bit
+    patterns [211,c], [211,c], [61,c] and c."""
+    import torch
+    c = int(np.ceil(d / 6) * 2)
+    c += c % 2
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, c, 2).float() / c))
+
+    def lut(n):
+        s = torch.arange(n, dtype=torch.float32)[:, None] * inv_freq[None, :]
+        e = torch.stack((s.sin(), s.cos()), dim=-1).flatten(-2, -1).to(torch.float16)
+        return np.ascontiguousarray(e.numpy().view(np.uint16))
+
+    return lut(211), lut(211), lut(61), c

@@ -1,0 +1,146 @@
+/*
+ * busca_hip.h - C-ABI of libbusca_hip.so, the MI355X (gfx950) implementation of BUSCA's per-frame
+ * track-recovery hot path.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * The reference (lorenzovaquero/BUSCA) has no FFI: its boundary is the Python surface of
+ * busca/network.py + busca/tracking.py.  Each entry point below names the reference code it replaces;
+ * busca_amd/ (Python, same names and semantics as the reference's `busca` package) binds them with ctypes.
+ *
+ * Conventions
+ *   - return 0 on success, negative BUSCA_E* on failure; busca_last_error(ctx) gives the message.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller (e.g. torch tensors' data_ptr()).
+ *     "host" pointers are ordinary host memory.  `stream` is a hipStream_t (NULL = default stream).
+ *   - one ctx per GPU/process; calls on one ctx are not re-entrant; no internal threads.
+ *   - all launches are asynchronous on `stream`; nothing here synchronises the device except
+ *     busca_ctx_destroy and the weight loaders.
+ */
+#ifndef BUSCA_HIP_H
+#define BUSCA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct busca_ctx busca_ctx;
+
+enum {
+    BUSCA_OK = 0,
+    BUSCA_EINVAL = -1,      /* bad argument / unsupported shape */
+    BUSCA_ENOWEIGHTS = -2,  /* forward called before the matching load_weights */
+    BUSCA_EHIP = -3,        /* a HIP runtime call failed */
+    BUSCA_ENOMEM = -4
+};
+
+enum { BUSCA_ACT_RELU = 0, BUSCA_ACT_GELU = 1 };
+/* arithmetic of the dense contractions; LayerNorm / softmax / residual stream are always f32 */
+enum { BUSCA_PREC_F32 = 0, BUSCA_PREC_F16 = 1 };
+enum { BUSCA_PAIR_CENTER = 0, BUSCA_PAIR_CENTER_WEIGHTED = 1, BUSCA_PAIR_IOU = 2, BUSCA_PAIR_IOU_COST = 3 };
+
+/* ---- context ------------------------------------------------------------------------------ */
+int busca_ctx_create(int device, busca_ctx** out);
+void busca_ctx_destroy(busca_ctx* ctx);
+const char* busca_last_error(const busca_ctx* ctx);
+/* Library/ABI version: major*1000 + minor. */
+int busca_version(void);
+
+/* ---- Decision Transformer (busca/network.py:176-244 without the ReID stage) ----------------- */
+typedef struct {
+    int32_t d;             /* trans_dim (network.py:17); 64, 256 or 512 */
+    int32_t ff;            /* ff_size */
+    int32_t nhead;         /* must be 4 (config/ **.yml:3) */
+    int32_t nlayers;       /* num_layer, <= 8 */
+    int32_t E;             /* dim_embedding of the ReID feature (512) */
+    int32_t activation;    /* BUSCA_ACT_*; the reference effectively runs RELU */
+    int32_t fake_bbox_f64; /* 1: candidate-side bucket math in float64 (reference's pinned numpy 1.23.5,
+                              busca/tracking.py:12 + busca/encodings.py:21,127); 0: float32 (numpy >= 2) */
+    int32_t precision;     /* BUSCA_PREC_* */
+} busca_dt_cfg;
+
+/* Number of float32 values in the flat weight blob for `cfg` (layout below). */
+size_t busca_dt_blob_floats(const busca_dt_cfg* cfg);
+
+/*
+ * Load Decision-Transformer weights (replaces nn.Module state held by busca/network.py:45-100 and
+ * BUSCA.load_pretrained, network.py:432-467).  `blob` is HOST float32, reference state_dict tensors
+ * concatenated in this order (row-major, torch layouts):
+ *   encoder.weight[d,E] encoder.bias[d] sep_token[d] non_token[d] bad_token[d]
+ *   for each layer: self_attn.in_proj_weight[3d,d] in_proj_bias[3d] out_proj.weight[d,d] out_proj.bias[d]
+ *                   linear1.weight[ff,d] linear1.bias[ff] linear2.weight[d,ff] linear2.bias[d]
+ *                   norm1.weight[d] norm1.bias[d] norm2.weight[d] norm2.bias[d]
+ *   decoder.0.weight[d] decoder.0.bias[d] decoder.1.weight[d] decoder.1.bias[1]
+ * `lut_xy`,`lut_sz` ([211, lut_c]) and `lut_t` ([61, lut_c]) are HOST IEEE fp16 bit patterns: the three
+ * per-axis sin/cos tables the reference's 211x211x61xd table factors into (busca/encodings.py:23-32).
+ * The library repacks the matrices into MFMA operand-fragment order and uploads everything.
+ */
+int busca_dt_load_weights(busca_ctx* ctx, const busca_dt_cfg* cfg, const float* blob, size_t blob_floats,
+                          const uint16_t* lut_xy, const uint16_t* lut_sz, const uint16_t* lut_t, int32_t lut_c);
+
+/*
+ * One association step for B lost tracks x P proposals (replaces BUSCA.forward network.py:203-232,
+ * PositionalEncoding.forward encodings.py:43-94 and the softmax/argmax of network.py:403,415-421).
+ * All pointers dev.  T = L + 2*(P+2).
+ *   mem_feat [B,L,E] f32, can_feat [B,P,E] f32 : ReID features (what reid_encoder returns)
+ *   mem_ltrb [B,L,4] f32, can_ltrb [B,P,4] f32 : boxes as passed to BUSCA.forward (ltrb)
+ *   logits   [B,P+2] f32  pre-softmax, order [slot_0..slot_{P-1}, NON, BAD]   (required)
+ *   probs    [B,P+2] f32  softmax(logits)                                      (may be NULL)
+ *   argmax   [B]     i32  first index of the row maximum of probs              (may be NULL)
+ *   hidden   [B,T,d] f32  transformer output (source of .logits/.mem_logits)   (may be NULL)
+ *   att      [nlayers,B,nhead,T,T] f32 per-head attention weights              (may be NULL)
+ */
+int busca_dt_forward(busca_ctx* ctx, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
+                     const float* can_ltrb, int32_t B, int32_t L, int32_t P, float* logits, float* probs,
+                     int32_t* argmax, float* hidden, float* att, void* stream);
+
+/* Bucket indices only (busca/encodings.py:150-235): ids [B,T,3] i32 = (xy, size, time) per token. */
+int busca_dt_bucket_ids(busca_ctx* ctx, const float* mem_ltrb, const float* can_ltrb, int32_t B, int32_t L,
+                        int32_t P, int32_t* ids, void* stream);
+
+/* Average duration in ms of the dt_forward kernel launches issued through this ctx since the last
+ * reset, measured with HIP events on the launch stream (used by bench.py's roofline leg).
+ * Enabling timing adds two event records per launch. */
+int busca_timing_enable(busca_ctx* ctx, int32_t on);
+int busca_timing_read(busca_ctx* ctx, double* avg_ms, int64_t* launches, int32_t reset);
+
+/* ---- proposal geometry (busca/tracking.py:23-60; adapters/.../matching.py:53-91,173-186) ------ */
+/*
+ * out[nA,nB] f64.  a,b: [n,4] f64 ltrb boxes (dev).  mode:
+ *   CENTER           euclidean distance between box centres (center_distance, weight_size=False)
+ *   CENTER_WEIGHTED  ... times max(sqrt(area_a)/sqrt(area_b), inverse)  (weight_size=True)
+ *   IOU              cython_bbox.bbox_overlaps ("+1" pixel convention)
+ *   IOU_COST         1 - IOU (iou_distance)
+ * scores_b (dev f64 [nB]) may be NULL; with IOU_COST it applies fuse_score: 1 - iou*score_b.
+ */
+int busca_pairwise(busca_ctx* ctx, const double* a, int32_t nA, const double* b, int32_t nB, int32_t mode,
+                   const double* scores_b, double* out, void* stream);
+
+/* idx[B,P] i32 = per-row indices of the P smallest values of dist[B,N] f64, ascending, ties by lower
+ * index; -1 pads rows when N < P (np.argsort(row)[:P] + None padding, network.py:333-338). */
+int busca_topk_rows(busca_ctx* ctx, const double* dist, int32_t B, int32_t N, int32_t P, int32_t* idx, void* stream);
+
+/* ---- crops (busca/tracking.py:62-113, busca/network.py:492-507) ------------------------------- */
+/*
+ * frame: dev u8 [H,W,3] (BGR, row stride `stride` bytes); boxes: dev f32 [n,4] x1y1x2y2.
+ * out_u8 (may be NULL): dev u8 [n,384,128,3] BGR - exactly get_image_crops(normalize=False).
+ * out_f16 (may be NULL): dev fp16 [n,384,128,4] RGB0 normalised ((x/255-mean)/std, ghost std), the
+ *   ReID input layout of busca_reid_forward_f16in.
+ */
+int busca_crop_gather(busca_ctx* ctx, const uint8_t* frame, int32_t H, int32_t W, int32_t stride,
+                      const float* boxes, int32_t n, uint8_t* out_u8, void* out_f16, void* stream);
+
+/* ---- ReID feature extractor (busca/network.py:510-575 + busca/reid/resnet.py:266-322) --------- */
+/* Number of float32 values in the ReID weight blob (layout: see busca_amd/weights.py:reid_blob). */
+size_t busca_reid_blob_floats(void);
+int busca_reid_load_weights(busca_ctx* ctx, const float* blob, size_t blob_floats);
+/* crops: dev u8 [n,384,128,3] BGR (what the trackers keep in images_mem).  feats: dev f32 [n,512],
+ * L2-normalised.  ONE CALL == ONE BatchNorm batch (train-mode statistics, network.py:553-556). */
+int busca_reid_forward(busca_ctx* ctx, const uint8_t* crops, int32_t n, float* feats, void* stream);
+/* Bytes of device workspace busca_reid_forward needs for n crops (allocated lazily inside the ctx). */
+size_t busca_reid_workspace_bytes(int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BUSCA_HIP_H */
