@@ -49,6 +49,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing - run `python -m busca_amd.build` (hipcc, gfx950). "
                               "busca_amd has no CPU fallback." % LIB_PATH)
+        # torch must be imported first: it bundles its own libamdhip64 (SONAME libamdhip64.so.7); when that
+        # copy is already loaded, this library's NEEDED libamdhip64.so.7 binds to it and both share ONE HIP
+        # runtime (same device pointers, same streams).  Loading in the other order gives two runtimes.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
@@ -70,7 +74,8 @@ class Context:
         h = _vp()
         rc = self.lib.busca_ctx_create(int(device), C.byref(h))
         if rc != 0 or not h.value:
-            raise BuscaError("busca_ctx_create(device=%d) failed with %d (is a GPU visible?)" % (device, rc))
+            raise BuscaError("busca_ctx_create(device=%d) failed with %d: %s" % (
+                device, rc, self.lib.busca_last_error(None).decode()))
         self.h = h
         self.device = int(device)
 

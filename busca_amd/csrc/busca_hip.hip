@@ -57,13 +57,20 @@ static int fail(busca_ctx* c, int code, const char* fmt, ...) {
 
 extern "C" int busca_version(void) { return 1000; }
 
+static std::string g_create_err;   // busca_last_error(NULL) reports why busca_ctx_create failed
+
 extern "C" int busca_ctx_create(int device, busca_ctx** out) {
     if (!out) return BUSCA_EINVAL;
     *out = nullptr;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BUSCA_EHIP;
-    if (device < 0 || device >= n) return BUSCA_EINVAL;
-    if (hipSetDevice(device) != hipSuccess) return BUSCA_EHIP;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e) + ", devices=" + std::to_string(n);
+        return BUSCA_EHIP;
+    }
+    if (device < 0 || device >= n) { g_create_err = "device index out of range"; return BUSCA_EINVAL; }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return BUSCA_EHIP; }
     busca_ctx* c = new busca_ctx();
     c->device = device;
     *out = c;
@@ -94,7 +101,7 @@ extern "C" void busca_ctx_destroy(busca_ctx* c) {
     delete c;
 }
 
-extern "C" const char* busca_last_error(const busca_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+extern "C" const char* busca_last_error(const busca_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 extern "C" int busca_timing_enable(busca_ctx* c, int32_t on) {
     if (!c) return BUSCA_EINVAL;

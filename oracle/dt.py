@@ -28,7 +28,18 @@ class DTConfig:
 
 
 def _t(sd):
+    if getattr(sd, "_oracle_prepared", False):
+        return sd
     return {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in sd.items()}
+
+
+class _Prepared(dict):
+    _oracle_prepared = True
+
+
+def prepare(sd):
+    """Convert a state dict to float32 torch tensors once (so timing loops do not re-convert)."""
+    return _Prepared(_t(sd))
 
 
 def assemble_tokens(sd, mem_e, can_e):
