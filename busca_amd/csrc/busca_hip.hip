@@ -38,6 +38,8 @@ struct busca_ctx {
     std::vector<hipEvent_t> ev_free;
     double t_ms = 0.0;
     long long t_n = 0;
+    int* crop_fill = nullptr;      // per-crop pad value scratch (busca_crop_gather)
+    int crop_fill_cap = 0;
 };
 
 static int fail(busca_ctx* c, int code, const char* fmt, ...) {
@@ -97,6 +99,7 @@ extern "C" void busca_ctx_destroy(busca_ctx* c) {
     timing_drain(c);
     for (auto e : c->ev_free) hipEventDestroy(e);
     if (c->dt.dev_blob) hipFree(c->dt.dev_blob);
+    if (c->crop_fill) hipFree(c->crop_fill);
     reid_free(c->reid);
     delete c;
 }

@@ -1,0 +1,72 @@
+"""Thin device-tensor wrappers over the geometry / crop entry points of libbusca_hip.so."""
+import numpy as np
+import torch
+
+from . import _lib
+
+_default_ctx = None
+
+
+def default_context(device=0):
+    """Process-wide Context (one per process/GPU, as the C-ABI prescribes)."""
+    global _default_ctx
+    if _default_ctx is None or _default_ctx.device != device:
+        _default_ctx = _lib.Context(device)
+    return _default_ctx
+
+
+def _dev(ctx):
+    return torch.device("cuda", ctx.device)
+
+
+def _stream(ctx):
+    return torch.cuda.current_stream(_dev(ctx)).cuda_stream
+
+
+def _f64(x, ctx):
+    if not torch.is_tensor(x):
+        x = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64)))
+    return x.to(device=_dev(ctx), dtype=torch.float64).contiguous().view(-1, 4) if x.numel() else torch.zeros(0, 4, dtype=torch.float64, device=_dev(ctx))
+
+
+def pairwise(ctx, a, b, mode, scores_b=None):
+    """[nA,4],[nB,4] float64 ltrb -> float64 [nA,nB] on the GPU (mode: _lib.PAIR_*)."""
+    a, b = _f64(a, ctx), _f64(b, ctx)
+    out = torch.zeros(a.shape[0], b.shape[0], dtype=torch.float64, device=_dev(ctx))
+    sc = None
+    if scores_b is not None:
+        sc = torch.as_tensor(np.asarray(scores_b, dtype=np.float64)).to(_dev(ctx)).contiguous()
+    ctx.check(ctx.lib.busca_pairwise(ctx.h, a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], int(mode),
+                                     _lib.ptr(sc), out.data_ptr(), _stream(ctx)))
+    return out
+
+
+def topk_rows(ctx, dist, P):
+    """float64 [B,N] -> int32 [B,P] indices of the P smallest per row (ties: lower index; -1 padding)."""
+    if not torch.is_tensor(dist):
+        dist = torch.from_numpy(np.ascontiguousarray(np.asarray(dist, dtype=np.float64)))
+    dist = dist.to(device=_dev(ctx), dtype=torch.float64).contiguous()
+    B, N = dist.shape
+    idx = torch.empty(B, P, dtype=torch.int32, device=_dev(ctx))
+    ctx.check(ctx.lib.busca_topk_rows(ctx.h, dist.data_ptr(), B, N, P, idx.data_ptr(), _stream(ctx)))
+    return idx
+
+
+def crop_gather(ctx, frame, boxes, want_u8=True, want_f16=False):
+    """frame: u8 [H,W,3] BGR (numpy or cuda tensor); boxes [n,4] x1y1x2y2 -> (u8 [n,384,128,3] | None,
+    fp16 [n,384,128,4] RGB0 normalised | None), both on the GPU."""
+    dev = _dev(ctx)
+    if not torch.is_tensor(frame):
+        frame = torch.from_numpy(np.ascontiguousarray(frame))
+    frame = frame.to(dev).contiguous()
+    assert frame.dtype == torch.uint8 and frame.dim() == 3 and frame.shape[2] == 3
+    if not torch.is_tensor(boxes):
+        boxes = torch.from_numpy(np.ascontiguousarray(np.asarray(boxes, dtype=np.float32).reshape(-1, 4)))
+    boxes = boxes.to(device=dev, dtype=torch.float32).contiguous()
+    n = boxes.shape[0]
+    H, W = frame.shape[:2]
+    u8 = torch.empty(n, 384, 128, 3, dtype=torch.uint8, device=dev) if want_u8 else None
+    f16 = torch.empty(n, 384, 128, 4, dtype=torch.float16, device=dev) if want_f16 else None
+    ctx.check(ctx.lib.busca_crop_gather(ctx.h, frame.data_ptr(), H, W, frame.stride(0), boxes.data_ptr(), n,
+                                        _lib.ptr(u8), _lib.ptr(f16), _stream(ctx)))
+    return u8, f16

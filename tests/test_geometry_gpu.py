@@ -1,0 +1,117 @@
+"""GPU parity (bit-exact): pairwise distance / IoU / top-P / crop kernels vs the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from busca_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from busca_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _boxes(seed, n, big=False):
+    cx = synth.uniform(seed, "cx", (n,), 0, 1920).astype(np.float64)
+    cy = synth.uniform(seed, "cy", (n,), 0, 1080).astype(np.float64)
+    h = synth.uniform(seed, "h", (n,), 10, 400).astype(np.float64)
+    w = h * synth.uniform(seed, "ar", (n,), 0.2, 0.6).astype(np.float64)
+    return np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+
+
+@pytest.mark.parametrize("nA,nB", [(1, 1), (32, 150), (128, 150), (17, 65), (300, 1000), (0, 5), (5, 0)])
+@pytest.mark.parametrize("mode", ["center", "center_w", "iou", "iou_cost", "fuse"])
+def test_pairwise_bit_exact(ctx, nA, nB, mode):
+    from busca_amd import _lib, geometry as G
+    from oracle import geometry as og
+    a, b = _boxes(1 + nA, nA), _boxes(2 + nB, nB)
+    if nA > 4 and nB > 4:
+        b[3] = a[2]            # identical boxes (IoU 1, distance 0)
+        b[4, 2:] = b[4, :2]    # zero-area box
+    sc = synth.uniform(9, "scores", (nB,), 0.1, 1.0).astype(np.float64)
+    if mode == "center":
+        got, ref = G.pairwise(ctx, a, b, _lib.PAIR_CENTER), og.center_distance(a, b)
+    elif mode == "center_w":
+        got, ref = G.pairwise(ctx, a, b, _lib.PAIR_CENTER_WEIGHTED), og.center_distance(a, b, weight_size=True)
+    elif mode == "iou":
+        got, ref = G.pairwise(ctx, a, b, _lib.PAIR_IOU), og.iou_matrix(a, b)
+    elif mode == "iou_cost":
+        got, ref = G.pairwise(ctx, a, b, _lib.PAIR_IOU_COST), og.iou_distance(a, b)
+    else:
+        got, ref = G.pairwise(ctx, a, b, _lib.PAIR_IOU_COST, scores_b=sc), og.fuse_score(og.iou_distance(a, b), sc)
+    got = got.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref, equal_nan=True)
+
+
+def test_center_distance_matches_scipy(ctx):
+    """The oracle's sqrt(dx*dx+dy*dy) is what scipy's cdist computes (busca/tracking.py:48)."""
+    from scipy.spatial.distance import cdist
+    from oracle import geometry as og
+    a, b = _boxes(5, 40), _boxes(6, 77)
+    ac = (a[:, :2] + a[:, 2:]) / 2.0
+    bc = (b[:, :2] + b[:, 2:]) / 2.0
+    assert np.array_equal(og.center_distance(a, b), cdist(ac, bc, metric="euclidean"))
+
+
+@pytest.mark.parametrize("B,N,P", [(32, 150, 16), (128, 150, 32), (3, 4, 16), (7, 0, 5), (64, 1000, 64), (1, 1, 1)])
+def test_topk_rows_bit_exact(ctx, B, N, P):
+    from busca_amd import geometry as G
+    from oracle import geometry as og
+    d = synth.uniform(B + N + P, "d", (B, N), 0, 500).astype(np.float64)
+    if N > 8:
+        d[:, 5] = d[:, 2]          # exact ties -> lower index first
+        d[0, 3] = np.inf
+        d[0, 4] = -0.0
+        d[0, 6] = 0.0
+    got = G.topk_rows(ctx, d, P).cpu().numpy()
+    ref = og.topk_rows(d, P)
+    assert np.array_equal(got, ref)
+
+
+def _frame(seed, H, W):
+    return synth.randint_u8(seed, "frame", (H, W, 3))
+
+
+def test_crop_gather_bit_exact(ctx):
+    """Device crops vs the oracle's restatement of cutout + OpenCV fixed-point bilinear (bit-exact between
+    the two restatements; both are +-1 LSB-unpinned against the real cv2, see oracle/geometry.py)."""
+    from busca_amd import geometry as G
+    from oracle import geometry as og
+    H, W = 540, 960
+    fr = _frame(3, H, W)
+    boxes = np.array([
+        [100.3, 50.2, 180.9, 300.7],      # interior, upscale in x, mixed in y
+        [-20.5, -30.0, 60.2, 200.0],      # clipped top-left -> mean padding
+        [900.0, 400.0, 1000.0, 600.0],    # clipped bottom-right
+        [10.0, 10.0, 138.0, 394.0],       # exactly 128 x 384 -> copy
+        [200.0, 100.0, 456.0, 868.0],     # 256 x 768 (clipped) -> exact 2x path with padding
+        [300.0, 20.0, 556.0, 532.0],      # 256 x 512
+        [5.5, 5.5, 6.2, 6.1],             # tiny 1x1 box
+        [2000.0, 2000.0, 2100.0, 2200.0], # fully outside: empty clipped crop, all padding (fill 0)
+        [50.0, 60.0, 50.0, 60.0],         # zero extent -> empty cutout -> zeros
+        [400.0, 100.0, 1000.0, 539.5],    # big downscale
+    ], dtype=np.float32)
+    u8, f16 = G.crop_gather(ctx, fr, boxes, want_u8=True, want_f16=True)
+    torch.cuda.synchronize()
+    got = u8.cpu().numpy()
+    for i, bx in enumerate(boxes):
+        ref = og.get_bbox_crop(fr, bx)
+        assert ref.shape == (384, 128, 3)
+        assert np.array_equal(got[i], ref), "crop %d differs (max %d)" % (i, np.abs(got[i].astype(int) - ref.astype(int)).max())
+    # normalised fp16 RGB0 layout == fp16(normalize_bgr(u8))[..., ::-1]
+    ref_n = og.normalize_bgr(got)[..., ::-1].astype(np.float16)
+    gn = f16.cpu().numpy()
+    assert np.array_equal(gn[..., :3], ref_n)
+    assert (gn[..., 3] == 0).all()
+
+
+def test_crop_gather_empty(ctx):
+    from busca_amd import geometry as G
+    u8, _ = G.crop_gather(ctx, _frame(1, 64, 64), np.zeros((0, 4), np.float32))
+    assert tuple(u8.shape) == (0, 384, 128, 3)
