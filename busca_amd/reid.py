@@ -1,0 +1,30 @@
+"""Host handle of the ReID feature extractor kernels (busca_reid_* in include/busca_hip.h)."""
+import numpy as np
+import torch
+
+from . import weights
+
+
+class ReIDEncoderHIP:
+    """ResNet-50 (max pool, red=4) with batch-statistics BatchNorm, fp16 MFMA convs.
+    `forward(crops_u8)`: u8 [n,384,128,3] BGR -> f32 [n,512] L2-normalised.  One call == one BN batch."""
+    PRETRAINED_SIZE = (384, 128)
+
+    def __init__(self, ctx, state_dict, prefix=""):
+        self.ctx = ctx
+        blob = weights.reid_blob(state_dict, prefix)
+        want = ctx.lib.busca_reid_blob_floats()
+        assert blob.size == want, (blob.size, want)
+        ctx.check(ctx.lib.busca_reid_load_weights(ctx.h, blob.ctypes.data, blob.size))
+
+    def forward(self, crops_u8, stream=None):
+        dev = torch.device("cuda", self.ctx.device)
+        if not torch.is_tensor(crops_u8):
+            crops_u8 = torch.from_numpy(np.ascontiguousarray(crops_u8))
+        crops_u8 = crops_u8.to(dev).contiguous()
+        assert crops_u8.dtype == torch.uint8 and tuple(crops_u8.shape[1:]) == (384, 128, 3), crops_u8.shape
+        n = crops_u8.shape[0]
+        feats = torch.empty(n, 512, device=dev)
+        s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        self.ctx.check(self.ctx.lib.busca_reid_forward(self.ctx.h, crops_u8.data_ptr(), n, feats.data_ptr(), s))
+        return feats

@@ -56,3 +56,27 @@ def encoding_luts(d):
         return np.ascontiguousarray(e.numpy().view(np.uint16))
 
     return lut(211), lut(211), lut(61), c
+
+
+def reid_conv_names():
+    """(conv key, bn key) in forward order - the order of the ReID blob (busca/reid/resnet.py:169-252)."""
+    names = [("conv1", "bn1")]
+    for li, nblk in enumerate((3, 4, 6, 3)):
+        for b in range(nblk):
+            p = "layer%d.%d." % (li + 1, b)
+            names += [(p + "conv1", p + "bn1"), (p + "conv2", p + "bn2"), (p + "conv3", p + "bn3")]
+            if b == 0:
+                names.append((p + "downsample.0", p + "downsample.1"))
+    return names
+
+
+def reid_blob(state_dict, prefix=""):
+    """ReID blob: per conv (forward order) weight[Cout,Cin,k,k], bn.weight, bn.bias; then red.weight, red.bias.
+    `prefix` is 'reid_encoder.model.' for a full BUSCA checkpoint.  BN running statistics and the unused
+    classifier `fc` are not part of the blob (train-mode BN never reads them, network.py:553-556)."""
+    parts = []
+    for conv, bn in reid_conv_names():
+        parts += [_np(state_dict[prefix + conv + ".weight"]).ravel(), _np(state_dict[prefix + bn + ".weight"]).ravel(),
+                  _np(state_dict[prefix + bn + ".bias"]).ravel()]
+    parts += [_np(state_dict[prefix + "red.weight"]).ravel(), _np(state_dict[prefix + "red.bias"]).ravel()]
+    return np.concatenate(parts)

@@ -1,0 +1,65 @@
+"""GPU parity: the HIP ReID extractor (fp16 MFMA convs, f32 accumulation and statistics) vs the float32
+oracle restatement of the reference's ResNet-50 with train-mode BatchNorm."""
+import numpy as np
+import pytest
+import torch
+
+from busca_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+# Stated tolerance of the fp16-operand path on L2-normalised 512-d features.  Emulating fp16 rounding of
+# weights + stored activations inside the float32 oracle (random weights, n=3) gives cosine 0.99927-0.99934
+# and max |delta| 6.5e-3 against the unrounded oracle; the kernel lands on the same figures, i.e. the
+# deviation is the rounding of the fp16 design, not a defect.
+FEAT_ATOL = 1e-2
+COS_MIN = 0.9990
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from busca_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def model(ctx):
+    from busca_amd.reid import ReIDEncoderHIP
+    sd = synth.reid_state_dict(3)
+    return ReIDEncoderHIP(ctx, sd), sd
+
+
+def _crops(seed, n):
+    """Smooth-ish random u8 crops (pure noise would make every crop statistically identical)."""
+    base = synth.randint_u8(seed, "crops", (n, 24, 8, 3)).astype(np.float32)
+    up = np.repeat(np.repeat(base, 16, axis=1), 16, axis=2)
+    noise = synth.randint_u8(seed, "noise", (n, 384, 128, 3)).astype(np.float32) - 128
+    return np.clip(up + 0.25 * noise, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("n", [3, 8])
+def test_reid_vs_oracle(model, n):
+    from oracle import reid as oreid
+    m, sd = model
+    crops = _crops(40 + n, n)
+    got = m.forward(crops).cpu().numpy()
+    ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
+    assert got.shape == (n, 512)
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-4)
+    cos = (got * ref).sum(1)
+    assert cos.min() >= COS_MIN, cos
+    assert np.abs(got - ref).max() <= FEAT_ATOL, np.abs(got - ref).max()
+
+
+def test_reid_batch_composition_matters(model):
+    """Train-mode BN: features depend on the batch they are computed in - and the kernel is
+    deterministic for a fixed batch."""
+    m, _ = model
+    crops = _crops(77, 6)
+    full = m.forward(crops).cpu().numpy()
+    again = m.forward(crops).cpu().numpy()
+    assert np.array_equal(full, again)
+    part = m.forward(crops[:3]).cpu().numpy()
+    assert np.abs(part - full[:3]).max() > 1e-4
