@@ -1,0 +1,343 @@
+"""`BUSCA` with the reference's public surface (busca/network.py:11-507), running on libbusca_hip.so.
+
+What stays on the host (Python): walking the tracker's track objects (`images_mem`, `tlwh_mem`, `scale`,
+`tlwh`) and scattering P+2 probabilities into the [B, N_det + B] matrix the trackers consume.
+What runs on the MI355X: top-P proposal selection, the ReID extractor (two train-mode-BN batches per
+step), token embed/assembly, bucket encoding, the 4 encoder layers, decoder, softmax and argmax.
+There is no CPU compute path: without the HIP library / a GPU every compute call raises.
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib, geometry, synth, tracking, weights
+from .dt import DecisionTransformerHIP
+from .reid import ReIDEncoderHIP
+
+_SUPPORTED_FLAVOUR = "MEM-SEP-CAN-BAD"
+_REID_PREFIX = "reid_encoder.model."
+_PIX_MEAN_RGB = np.array([0.485, 0.456, 0.406], dtype=np.float64)
+_PIX_STD_RGB = np.array([0.299, 0.224, 0.225], dtype=np.float64)
+
+
+def memory_indices(n_hist, seq_len, use_broader_memory):
+    """Which history entries form a track's memory (busca/network.py:247-275): the last `seq_len`, or - with
+    `use_broader_memory` and a long enough history - `seq_len` entries spread evenly from first to last."""
+    if use_broader_memory and n_hist >= seq_len and seq_len > 1:
+        step = float(n_hist - 1) / float(seq_len - 1)
+        return [int(i * step) for i in range(seq_len)]
+    return list(range(max(0, n_hist - seq_len), n_hist))
+
+
+class _ReIDFacade:
+    """`model.reid_encoder`: callable like the reference's ReID_Encoder (network.py:510-575): returns
+    (None, feats[n,512]); accepts u8 BGR [n,384,128,3] crops or normalised float RGB [n,3,384,128]."""
+    PRETRAINED_SIZE = (384, 128)
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def __call__(self, x):
+        return None, self._owner._reid_features(x)
+
+    forward = __call__
+    get_features = __call__
+
+
+class BUSCA:
+    def __init__(self, args):
+        self.args = args
+        self.dim_embedding = args.dim_embedding
+        self.dim_model = args.trans_dim
+        if args.activation not in ("relu", "gelu", "tanh", "silu"):
+            raise RuntimeError("activation should be relu/gelu/tanh/silu, not {}".format(args.activation))
+        if args.input_flavour != _SUPPORTED_FLAVOUR:
+            raise NotImplementedError('Input flavour "{}" not implemented'.format(args.input_flavour))
+        if getattr(args, "output_flavour", "CAN") != "CAN" or not args.encode_separator_as_reference or args.encode_special_tokens:
+            raise NotImplementedError("only output_flavour=CAN, encode_separator_as_reference=true, "
+                                      "encode_special_tokens=false (all shipped configs) are built")
+        if args.nhead != 4 or args.dim_embedding != 512:
+            raise NotImplementedError("nhead must be 4 and dim_embedding 512 (all shipped configs)")
+        # The reference's cloned encoder layers run ReLU whatever `activation` says (deepcopy +
+        # TransformerEncoderLayer.__setstate__, custom_layers.py:24-27,44-45).  Set
+        # args.fix_activation_quirk = True to run the configured activation instead (gelu only).
+        self.effective_activation = "relu"
+        if getattr(args, "fix_activation_quirk", False):
+            if args.activation not in ("relu", "gelu"):
+                raise NotImplementedError("only relu/gelu are built")
+            self.effective_activation = args.activation
+        self.precision = getattr(args, "precision", os.environ.get("BUSCA_AMD_PRECISION", "f32"))
+        self.pinned_numpy = bool(getattr(args, "pinned_numpy_semantics", True))
+        self.store_logits = False           # set True to fill .logits / .mem_logits like the reference does
+        self.expected_image_size = _ReIDFacade.PRETRAINED_SIZE
+        self.reid_encoder = _ReIDFacade(self)
+        self.attentions = None
+        self.logits = None
+        self.mem_logits = None
+        self._device_index = self._index_of(getattr(args, "device", None))
+        self._ctx = None
+        self._dt = None
+        self._reid = None
+        self._dirty = True
+        seed = int(getattr(args, "seed", 0))
+        sd = OrderedDict(synth.dt_state_dict(seed, d=args.trans_dim, ff=args.ff_size, nlayers=args.num_layer))
+        reid_sd = None
+        path = getattr(args, "reid_weights_file", "no")
+        if path is not None and path != "no":
+            reid_sd = self._read_checkpoint(path)
+            reid_sd = {k: v for k, v in reid_sd.items() if "fc" not in k.split(".") and "fc_person" not in k.split(".")}
+        base = synth.reid_state_dict(seed)
+        if reid_sd is not None:
+            base.update({k: np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v, dtype=np.float32)
+                         for k, v in reid_sd.items() if k in base})
+        for k, v in base.items():
+            sd[_REID_PREFIX + k] = v
+        self._sd = sd
+
+    # ---- nn.Module-like surface -------------------------------------------------------------------------
+    @staticmethod
+    def _index_of(device):
+        if device is None:
+            return 0
+        if isinstance(device, torch.device):
+            if device.type != "cuda":
+                raise RuntimeError("busca_amd has no CPU path; args.device must be a cuda device")
+            return device.index or 0
+        if isinstance(device, str):
+            return BUSCA._index_of(torch.device("cuda" if device in ("gpu", "cuda") else device))
+        return int(device)
+
+    def to(self, device):
+        idx = self._index_of(device)
+        if idx != self._device_index:
+            self._device_index, self._ctx, self._dt, self._reid, self._dirty = idx, None, None, None, True
+        return self
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def state_dict(self):
+        return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._sd.items())
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            if k in self._sd:
+                arr = np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v, dtype=np.float32)
+                if arr.shape != self._sd[k].shape:
+                    raise RuntimeError("size mismatch for {}: {} vs {}".format(k, arr.shape, self._sd[k].shape))
+                self._sd[k] = np.ascontiguousarray(arr)
+        self._dirty = True
+
+    @property
+    def num_params(self):
+        return int(sum(v.size for v in self._sd.values()))
+
+    num_trainable_params = num_params
+
+    @staticmethod
+    def _read_checkpoint(path):
+        ck = torch.load(path, map_location=torch.device("cpu"))
+        return ck["model_state_dict"] if "model_state_dict" in ck else ck
+
+    def load_pretrained(self, path, ignore_reid=False, ignore_reid_fc=False):
+        """busca/network.py:432-467: raw state_dict or {'model_state_dict': ...}; optional dropping of the
+        ReID classifier / the whole ReID; keys this model lacks (cls_token, fc, BN buffers) are ignored."""
+        sd = self._read_checkpoint(path)
+        if ignore_reid_fc:
+            sd = {k: v for k, v in sd.items() if "reid_encoder.model.fc." not in k and "reid_encoder.model.fc_person." not in k}
+        if ignore_reid:
+            sd = {k: v for k, v in sd.items() if "reid_encoder.model." not in k}
+        if "cls_token" in sd:
+            print("WARNING: Loading a model with a cls_token, but the current model does not have a cls_token. The cls_token will be ignored")
+        self.load_state_dict({k: v for k, v in sd.items() if k in self._sd})
+
+    # ---- device state ---------------------------------------------------------------------------------------
+    def _sync(self):
+        if self._ctx is None:
+            self._ctx = geometry.default_context(self._device_index)
+        if self._dirty:
+            dt_sd = {k: v for k, v in self._sd.items() if not k.startswith(_REID_PREFIX)}
+            self._dt = DecisionTransformerHIP(self._ctx, dt_sd, activation=self.effective_activation,
+                                              fake_bbox_f64=self.pinned_numpy, precision=self.precision)
+            self._reid = ReIDEncoderHIP(self._ctx, self._sd, prefix=_REID_PREFIX)
+            self._dirty = False
+        return self._ctx
+
+    def _dev(self):
+        return torch.device("cuda", self._device_index)
+
+    def _to_u8_hwc_bgr(self, x):
+        """Accept u8 BGR [...,384,128,3] or the reference's normalised float RGB [...,3,384,128]; the latter is
+        mapped back to the u8 crop it was made from (the normalisation is injective on 0..255)."""
+        if not torch.is_tensor(x):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        x = x.to(self._dev())
+        if x.dtype == torch.uint8:
+            return x.reshape(-1, 384, 128, 3).contiguous()
+        x = x.reshape(-1, 3, 384, 128).double()
+        mean = torch.tensor(_PIX_MEAN_RGB, device=x.device).view(1, 3, 1, 1)
+        std = torch.tensor(_PIX_STD_RGB, device=x.device).view(1, 3, 1, 1)
+        u8 = torch.round((x * std + mean) * 255.0).clamp_(0, 255).to(torch.uint8)
+        return u8.flip(1).permute(0, 2, 3, 1).contiguous()          # RGB CHW -> BGR HWC
+
+    def _reid_features(self, x):
+        self._sync()
+        return self._reid.forward(self._to_u8_hwc_bgr(x))
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    def forward(self, embeddings_memory, candidate_embedding, memory_bboxes=None, candidates_bboxes=None,
+                return_att=False, return_logits=False, plot_results=False):
+        """busca/network.py:176-244.  Images: u8 BGR [B,n,384,128,3] or normalised float RGB [B,n,3,384,128];
+        boxes ltrb [B,n,4].  Returns the pre-softmax logits [B,P+2] (a cuda tensor)."""
+        if plot_results:
+            raise NotImplementedError("plot_results needs the reference's OpenCV visualisation")
+        self._sync()
+        B, L = int(embeddings_memory.shape[0]), int(embeddings_memory.shape[1])
+        P = int(candidate_embedding.shape[1])
+        mem_feat = self._reid.forward(self._to_u8_hwc_bgr(embeddings_memory)).view(B, L, -1)   # BN batch 1 (network.py:192)
+        can_feat = self._reid.forward(self._to_u8_hwc_bgr(candidate_embedding)).view(B, P, -1)  # BN batch 2 (:193)
+        out = self._dt.forward(mem_feat, can_feat, memory_bboxes, candidates_bboxes,
+                               want_hidden=return_logits, want_att=return_att)
+        self._last = out
+        if return_att:
+            self.attentions = [out["att"][i] for i in range(out["att"].shape[0])]
+        if return_logits:
+            pos = [L + 2 * j + 1 for j in range(P + 2)]
+            self.logits = out["hidden"][:, pos]
+            self.mem_logits = out["hidden"][:, :L].mean(dim=1)
+        return out["logits"]
+
+    __call__ = forward
+
+    def forward_features(self, mem_feat, can_feat, memory_bboxes, candidates_bboxes, return_att=False, return_logits=False):
+        """Decision-Transformer step on precomputed 512-d ReID features (the 'DT-step' of bench.py)."""
+        self._sync()
+        out = self._dt.forward(mem_feat, can_feat, memory_bboxes, candidates_bboxes, want_hidden=return_logits, want_att=return_att)
+        self._last = out
+        return out
+
+    # ---- batching of tracker objects (busca/network.py:282-429) ------------------------------------------
+    def associate_embeddings(self, tracks_embeddings, dets_embeddings, dists_matrix, seq_len, num_candidates,
+                             use_broader_memory, select_highest_candidate, highest_candidate_minimum_thresh=None,
+                             keep_highest_value=False, extra_kalman_candidates=[], plot_results=False, normalize_ims=False):
+        B, N, P, L = len(tracks_embeddings), len(dets_embeddings), int(num_candidates), int(seq_len)
+        K = len(extra_kalman_candidates)
+        if B == 0 or (N == 0 and K == 0):
+            return None, None
+        self._sync()
+        H, W = self.expected_image_size
+
+        def as_u8(img):
+            img = np.asarray(img)
+            if img.dtype == np.uint8:
+                return img
+            # already-normalised float crops (normalize_ims=False callers): map back to the u8 they came from
+            v = np.rint((img.astype(np.float64) * tracking._PIXEL_STD + tracking._PIXEL_MEAN) * 255.0)
+            return np.clip(v, 0, 255).astype(np.uint8)
+
+        mem_u8 = np.zeros((B, L, H, W, 3), np.uint8)
+        mem_box = np.empty((B, L, 4), np.float64)
+        reliable = np.zeros(B, bool)
+        for t, trk in enumerate(tracks_embeddings):
+            hist = trk.images_mem
+            idx = memory_indices(len(hist), L, use_broader_memory)
+            if len(idx) == L:
+                for j, i in enumerate(idx):
+                    mem_u8[t, j] = as_u8(hist[i])
+                    mem_box[t, j] = np.asarray(trk.tlwh_mem[i], dtype=np.float64) * trk.scale
+                reliable[t] = True
+            else:                               # incomplete memory: zero crops, dummy box, flagged unreliable
+                mem_box[t] = (250.0, 250.0, 500.0, 500.0)
+
+        # top-P nearest detections per track on the GPU (ascending centre distance, ties by lower index)
+        order = np.full((B, P), -1, np.int64)
+        if N > 0:
+            d = np.ascontiguousarray(np.asarray(dists_matrix, dtype=np.float64).reshape(B, N))
+            order = geometry.topk_rows(self._ctx, d, P).cpu().numpy().astype(np.int64)
+        miss = tracking.missing_candidate_bbox(flavour="ltwh", pinned_numpy=self.pinned_numpy).astype(np.float64)
+        can_u8 = np.zeros((B, P, H, W, 3), np.uint8)
+        can_box = np.empty((B, P, 4), np.float64)
+        can_box[:] = miss
+        det_img = [None] * N
+        det_box = np.empty((N, 4), np.float64)
+        for di in np.unique(order[order >= 0]):
+            det = dets_embeddings[di]
+            det_img[di] = as_u8(det.images_mem[-1])
+            det_box[di] = np.asarray(det.tlwh_mem[-1], dtype=np.float64) * det.scale
+        for t in range(B):
+            for j in range(P):
+                di = order[t, j]
+                if di >= 0:
+                    can_u8[t, j] = det_img[di]
+                    can_box[t, j] = det_box[di]
+        n_avail = min(N, P)
+        if K > 0:                               # the track's own Kalman prediction takes slot min(N, P-1)
+            n_avail = min(N + 1, P)
+            slot = min(N, P - 1)
+            for t in range(B):
+                kd = extra_kalman_candidates[t]
+                order[t, slot] = N + t
+                can_box[t, slot] = np.asarray(kd.tlwh, dtype=np.float64) * kd.scale
+                can_u8[t, slot] = as_u8(kd.images_mem[-1])
+
+        with np.errstate(over="ignore"):
+            mem_ltrb = mem_box.astype(np.float32)
+            can_ltrb = can_box.astype(np.float32)
+            mem_ltrb[..., 2:] += mem_ltrb[..., :2]
+            can_ltrb[..., 2:] += can_ltrb[..., :2]
+
+        dev = self._dev()
+        mem_feat = self._reid.forward(torch.from_numpy(mem_u8.reshape(B * L, H, W, 3)).to(dev)).view(B, L, -1)
+        can_feat = self._reid.forward(torch.from_numpy(can_u8.reshape(B * P, H, W, 3)).to(dev)).view(B, P, -1)
+        out = self._dt.forward(mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=self.store_logits)
+        self._last = out
+        if self.store_logits:
+            pos = [L + 2 * j + 1 for j in range(P + 2)]
+            self.logits = out["hidden"][:, pos]
+            self.mem_logits = out["hidden"][:, :L].mean(dim=1)
+        probs = out["probs"].cpu().numpy().astype(np.float64)
+        best = out["argmax"].cpu().numpy()
+
+        cols = N if K == 0 else N + K
+        probs_matrix = np.zeros((B, cols))
+        rows = np.arange(B)
+        if select_highest_candidate:
+            top = probs[rows, best]
+            th = highest_candidate_minimum_thresh
+            ok = np.ones(B, bool) if (th is None or th == 0) else ((th > 0.0) & (top >= th))
+            picked = np.zeros_like(probs)
+            picked[rows[ok], best[ok]] = top[ok] if keep_highest_value else 1.0
+            probs = picked
+        for t in range(B):
+            probs_matrix[t, order[t, :n_avail]] = probs[t, :n_avail]
+        return probs_matrix, reliable
+
+    # ---- helpers with the reference's names ------------------------------------------------------------------
+    def _get_track_mem(self, track, seq_len, use_broader_memory):
+        idx = memory_indices(len(track.images_mem), seq_len, use_broader_memory)
+        return [track.images_mem[i] for i in idx], np.array([track.tlwh_mem[i] for i in idx]) * track.scale
+
+    def _normalize_embeddings_batch(self, embeddings_batch):
+        return tracking.normalize_crops(embeddings_batch)
+
+    @staticmethod
+    def ltwh_to_ltrb(ltwh):
+        ret = torch.clone(ltwh)
+        ret[..., 2:] += ret[..., :2]
+        return ret
+
+    def get_image_crops(self, image, bboxes, output_size=None, normalize=True):
+        """busca/network.py:492-507: all boxes of a frame cut, padded and resized on the GPU in one launch."""
+        if output_size is not None and tuple(output_size) != (self.expected_image_size[1], self.expected_image_size[0]):
+            raise NotImplementedError("only the ReID crop size 128x384 is built")
+        self._sync()
+        return tracking.get_image_crops(image, bboxes, normalize=normalize, ctx=self._ctx)
+
+
+class ReID_Encoder(_ReIDFacade):
+    """Name kept for importers of busca.network.ReID_Encoder."""

@@ -1,0 +1,88 @@
+"""Proposal-side geometry with the reference's names and semantics (busca/tracking.py), computed by the
+HIP kernels behind the C-ABI (busca_pairwise / busca_crop_gather).  Inputs and outputs are host numpy
+arrays exactly like the reference; there is no CPU implementation here."""
+import numpy as np
+import torch
+
+from . import _lib, geometry
+
+_F32_MIN = np.finfo("float32").min
+
+
+def missing_candidate_bbox(seq_len=None, flavour="ltrb", pinned_numpy=True):
+    """Sentinel box of a padded candidate (busca/tracking.py:7-20).  `pinned_numpy=True` reproduces the
+    reference's pinned numpy 1.23.5, where np.float32 / 100.0 is float64 and the array therefore float64."""
+    dt = np.float64 if pinned_numpy else np.float32
+    m = dt(_F32_MIN)
+    if flavour == "ltrb":
+        bbox = np.array([m, m, m / dt(100.0), m / dt(100.0)], dtype=dt)
+    elif flavour == "ltwh":
+        bbox = np.array([m, m, -m / dt(100.0), -m / dt(100.0)], dtype=dt)
+    else:
+        raise ValueError("Unknown flavour: {}".format(flavour))
+    if seq_len is not None:
+        bbox = np.tile(bbox, (seq_len, 1))
+    return bbox
+
+
+def _tlbrs(items):
+    if len(items) > 0 and isinstance(items[0], np.ndarray):
+        return np.asarray(items, dtype=np.float64).reshape(-1, 4)
+    return np.array([t.tlbr for t in items], dtype=np.float64).reshape(-1, 4)
+
+
+def center_distance(atracks, btracks, weight_size=False, ctx=None):
+    """Centre-to-centre distance matrix [len(a), len(b)] float64 (busca/tracking.py:23-60); accepts track
+    objects (`.tlbr`) or ndarrays.  Empty input -> zeros (the reference's np.float alias is float64)."""
+    a, b = _tlbrs(atracks), _tlbrs(btracks)
+    if len(a) == 0 or len(b) == 0:
+        return np.zeros((len(atracks), len(btracks)), dtype=np.float64)
+    ctx = ctx or geometry.default_context()
+    mode = _lib.PAIR_CENTER_WEIGHTED if weight_size else _lib.PAIR_CENTER
+    out = geometry.pairwise(ctx, a, b, mode)
+    return out.cpu().numpy()
+
+
+def iou_distance(atlbrs, btlbrs, det_scores=None, ctx=None):
+    """1 - IoU cost matrix with the '+1' pixel convention of cython_bbox (adapters/ByteTrack/yolox/tracker/
+    matching.py:53-91); with `det_scores` also applies fuse_score (:173-186)."""
+    a, b = _tlbrs(atlbrs), _tlbrs(btlbrs)
+    if len(a) == 0 or len(b) == 0:
+        return np.zeros((len(a), len(b)), dtype=np.float64)
+    ctx = ctx or geometry.default_context()
+    return geometry.pairwise(ctx, a, b, _lib.PAIR_IOU_COST, scores_b=det_scores).cpu().numpy()
+
+
+_PIXEL_MEAN = np.array([0.406, 0.456, 0.485])   # BGR
+_PIXEL_STD = np.array([0.225, 0.224, 0.299])    # BGR; 0.299 is the reference's "ghost" normalisation
+
+
+def normalize_crops(u8):
+    """(x/255 - mean)/std in BGR order, float32 (busca/network.py:470-478)."""
+    x = np.asarray(u8).astype(np.float32) / 255.0
+    x -= _PIXEL_MEAN
+    x /= _PIXEL_STD
+    return x
+
+
+def get_image_crops(im, bboxes, normalize=True, ctx=None):
+    """All crops of one frame in one launch: u8 BGR [N,384,128,3] (float32 normalised if `normalize`)."""
+    bboxes = np.asarray(bboxes, dtype=np.float32).reshape(-1, 4)
+    if len(bboxes) == 0:
+        return np.zeros([0, 128, 384, 3])            # the reference's (transposed) empty shape, network.py:503
+    ctx = ctx or geometry.default_context()
+    u8, _ = geometry.crop_gather(ctx, im, bboxes, want_u8=True)
+    crops = u8.cpu().numpy()
+    return normalize_crops(crops) if normalize else crops
+
+
+def get_bbox_crop(im, bbox_real_scale, output_size=(128, 384), normalize=True, ghost_normalize=True, ctx=None):
+    """Single crop (busca/tracking.py:62-78).  Only the 128x384 ReID geometry is built."""
+    if tuple(output_size) != (128, 384):
+        raise NotImplementedError("only output_size=(128, 384) is supported")
+    crop = get_image_crops(im, [bbox_real_scale], normalize=False, ctx=ctx)[0]
+    if normalize:
+        crop = crop.astype(np.float32) / 255.0
+        crop -= _PIXEL_MEAN
+        crop /= (_PIXEL_STD if ghost_normalize else np.array([0.225, 0.224, 0.229]))
+    return crop

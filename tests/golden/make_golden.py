@@ -132,6 +132,182 @@ def make_dt(ref):
         print("wrote", name, {k: v.shape for k, v in out.items() if k.startswith("logits")})
 
 
+class FakeTrack:
+    """Track protocol of associate_embeddings."""
+    def __init__(self, tlwh_hist, images, scale=1.0):
+        self.tlwh_mem = [np.asarray(b, dtype=np.float64) for b in tlwh_hist]
+        self.images_mem = list(images)
+        self.scale = scale
+        self.tlwh = self.tlwh_mem[-1]
+
+    @property
+    def tlbr(self):
+        r = self.tlwh.copy()
+        r[2:] += r[:2]
+        return r
+
+
+def smooth_crops(seed, n):
+    """Smooth-ish random u8 crops [n,384,128,3] (pure noise would make every crop statistically identical)."""
+    base = synth.randint_u8(seed, "crops", (n, 24, 8, 3)).astype(np.float32)
+    up = np.repeat(np.repeat(base, 16, axis=1), 16, axis=2)
+    noise = synth.randint_u8(seed, "noise", (n, 384, 128, 3)).astype(np.float32) - 128
+    return np.clip(up + 0.25 * noise, 0, 255).astype(np.uint8)
+
+
+def assoc_scene(seed, hist_lens, n_det, with_kalman):
+    """Deterministic fake tracks / detections (u8 crops from the portable PRNG)."""
+    def rng_boxes(name, n):
+        return np.stack([synth.uniform(seed, name + "x", (n,), 50, 1500), synth.uniform(seed, name + "y", (n,), 50, 800),
+                         synth.uniform(seed, name + "w", (n,), 30, 120), synth.uniform(seed, name + "h", (n,), 80, 300)], 1).astype(np.float64)
+    tracks = []
+    for t, hl in enumerate(hist_lens):
+        base = rng_boxes("trk%d" % t, 1)[0]
+        hist = [base + np.array([2.0 * i, 1.0 * i, 0.3 * i, 0.5 * i]) for i in range(hl)]
+        tracks.append(FakeTrack(hist, list(smooth_crops(seed * 100 + t, hl)), scale=1.0 + 0.25 * (t % 2)))
+    det_boxes = rng_boxes("det", max(n_det, 1))[:n_det]
+    for i in range(min(n_det, len(tracks))):          # put some detections near tracks
+        det_boxes[i] = tracks[i].tlwh_mem[-1] + np.array([5.0, -3.0, 2.0, 4.0])
+    det_imgs = smooth_crops(seed * 100 + 50, max(n_det, 1))
+    dets = [FakeTrack([det_boxes[i]], [det_imgs[i]], scale=1.0) for i in range(n_det)]
+    kal = []
+    if with_kalman:
+        kimgs = smooth_crops(seed * 100 + 60, len(tracks))
+        kal = [FakeTrack([tr.tlwh_mem[-1] + np.array([1.0, 1.0, 0.0, 0.0])], [kimgs[i]], scale=tr.scale) for i, tr in enumerate(tracks)]
+    return tracks, dets, kal
+
+
+def make_enc(ref):
+    """Bucket indices for seeded + adversarial boxes in both dtype modes, and rows of the real table vs LUT."""
+    _, _, ref_enc = ref
+    out = {}
+    for d in (12, 64):
+        pe = ref_enc.PositionalEncoding(d, input_flavour="MEM-SEP-CAN-BAD", dropout=0.1, encode_sep_as_ref=True,
+                                        batch_first=True, device="cpu")
+        idx = np.array([[0, 0, 0], [210, 210, 60], [87, 100, 10], [2, 105, 32], [179, 210, 34], [100, 210, 34], [105, 1, 59]])
+        out["pe_idx_d%d" % d] = idx
+        out["pe_rows_d%d" % d] = np.stack([pe.pe[i, j, k].numpy().view(np.uint16) for i, j, k in idx])
+        if d == 64:
+            inp = synth.dt_inputs(31, 24, 11, 16, sentinel_every=6)
+            mb, cb = inp["mem_boxes"].copy(), inp["can_boxes"].copy()
+            # adversarial: candidates that sit exactly on / next to the reference box, degenerate boxes
+            cb[1, 0] = mb[1, -1]
+            cb[1, 1] = mb[1, -1] + np.array([1e-3, 0, 1e-3, 0], np.float32)
+            cb[2, 0] = np.array([100, 100, 100, 100], np.float32)      # zero-area box
+            cb[2, 1] = mb[2, -1] * 4.0
+            mb[3, 0] = mb[3, -1]
+            out["ids_mem_boxes"], out["ids_can_boxes"] = mb, cb
+            mem = torch.zeros(24, 11, d)
+            can = torch.zeros(24, 2 * 18, d)
+            for mode, f64 in (("f64", True), ("f32", False)):
+                m = types.SimpleNamespace(pos_encoder=pe)
+                set_fake_dtype(m, f64)
+                mbt, cbt = torch.from_numpy(mb), torch.from_numpy(cb)
+                fakes = pe._insert_fake_bboxes(can=can, can_bboxes=cbt, ref_bbox=mbt[:, -1:, :].clone(), num_candidates=18, encode_sep_as_ref=True)
+                mt, ct = pe._get_temporal_ids(mem=mem, can=can, num_candidates=18)
+                (mxy, msz), (cxy, csz) = pe._get_spatial_ids(mem_bboxes=mbt, can_bboxes=fakes)
+                ids = torch.stack([torch.cat([mxy, cxy], 1), torch.cat([msz, csz], 1), torch.cat([mt, ct], 1)], -1)
+                out["ids_" + mode] = ids.numpy().astype(np.int32)
+        del pe
+    np.savez_compressed(os.path.join(OUT, "enc.npz"), **out)
+    print("wrote enc", {k: v.shape for k, v in out.items()})
+
+
+def make_geom(ref):
+    ref_network, ref_tracking, _ = ref
+    out = {}
+    a = np.stack([synth.uniform(5, "ax", (40,), 0, 1900), synth.uniform(5, "ay", (40,), 0, 1000)], 1).astype(np.float64)
+    a = np.concatenate([a, a + np.stack([synth.uniform(5, "aw", (40,), 10, 200), synth.uniform(5, "ah", (40,), 20, 400)], 1)], 1)
+    b = np.stack([synth.uniform(6, "bx", (77,), 0, 1900), synth.uniform(6, "by", (77,), 0, 1000)], 1).astype(np.float64)
+    b = np.concatenate([b, b + np.stack([synth.uniform(6, "bw", (77,), 10, 200), synth.uniform(6, "bh", (77,), 20, 400)], 1)], 1)
+    out["a"], out["b"] = a, b
+    out["center"] = ref_tracking.center_distance(a, b)
+    out["center_w"] = ref_tracking.center_distance(a, b, weight_size=True)
+    out["missing_ltrb"] = ref_tracking.missing_candidate_bbox(flavour="ltrb")
+    out["missing_ltwh"] = ref_tracking.missing_candidate_bbox(flavour="ltwh")
+    # memory sampling (network.py:247-279)
+    gm = ref_network.BUSCA._get_track_mem
+    rows = []
+    for n_hist in (1, 3, 10, 11, 12, 15, 40, 101):
+        for seq_len in (1, 5, 11):
+            for broader in (True, False):
+                trk = types.SimpleNamespace(images_mem=list(range(n_hist)), tlwh_mem=[np.zeros(4)] * n_hist, scale=1.0)
+                mem, _ = gm(None, trk, seq_len, broader)
+                rows.append([n_hist, seq_len, int(broader)] + list(mem) + [-1] * (11 - len(mem)))
+    out["track_mem"] = np.array(rows, dtype=np.int64)
+    # cutout geometry + mean fill without the (third-party) resize
+    fr = synth.randint_u8(3, "frame", (540, 960, 3))
+    boxes = np.array([[100.3, 50.2, 180.9, 300.7], [-20.5, -30.0, 60.2, 200.0], [900.0, 400.0, 1000.0, 600.0],
+                      [10.0, 10.0, 138.0, 394.0], [5.5, 5.5, 6.2, 6.1], [400.0, 100.0, 1000.0, 539.5]], dtype=np.float32)
+    out["cut_boxes"] = boxes
+    for i, bx in enumerate(boxes):
+        cut = ref_tracking._cutout_with_pad(fr, bx)
+        out["cut_shape_%d" % i] = np.array(cut.shape)
+        out["cut_sum_%d" % i] = np.array([int(cut.astype(np.int64).sum()), int(cut[0, 0, 0]), int(cut[-1, -1, 2])])
+    np.savez_compressed(os.path.join(OUT, "geom.npz"), **out)
+    print("wrote geom")
+
+
+def load_reid_weights(enc, seed):
+    full = enc.model.state_dict()
+    for k, v in synth.reid_state_dict(seed).items():
+        assert tuple(full[k].shape) == tuple(v.shape), k
+        full[k] = torch.from_numpy(v)
+    enc.model.load_state_dict(full)
+
+
+def make_reid(ref):
+    ref_network = ref[0]
+    enc = ref_network.ReID_Encoder(num_classes=299, device=torch.device("cpu"), pretrained_path="no",
+                                   use_domain_adaptation=True, trainable=False, use_checkpointing=False)
+    load_reid_weights(enc, 3)
+    out = {}
+    for n, seed in ((3, 43), (5, 45)):
+        crops = smooth_crops(seed, n)
+        x = crops.astype(np.float32) / 255.0
+        x -= np.array([0.406, 0.456, 0.485])
+        x /= np.array([0.225, 0.224, 0.299])
+        xt = torch.from_numpy(x).float()[..., [2, 1, 0]].permute(0, 3, 1, 2)
+        _, feats = enc(xt)
+        out["feats_n%d_seed%d" % (n, seed)] = feats.numpy()
+    np.savez_compressed(os.path.join(OUT, "reid.npz"), **out)
+    print("wrote reid", {k: v.shape for k, v in out.items()})
+
+
+ASSOC_CASES = [("a", [15, 3, 11], 3, True, 5), ("b", [12, 30], 8, True, 5), ("c", [11, 11, 20], 4, False, 5), ("d", [13], 0, True, 5)]
+
+
+def make_assoc(ref):
+    """associate_embeddings end to end (reference ReID + DT on CPU, float32) on fake tracker objects."""
+    ref_network, ref_tracking, _ = ref
+    d, ff, seed = 64, 128, 17
+    model = build_ref_model(ref_network, d, ff)
+    load_dt_weights(model, synth.dt_state_dict(seed, d=d, ff=ff))
+    model.reid_encoder = ref_network.ReID_Encoder(num_classes=299, device=torch.device("cpu"), pretrained_path="no",
+                                                  use_domain_adaptation=True, trainable=False, use_checkpointing=False)
+    load_reid_weights(model.reid_encoder, seed)
+    out = {}
+    for ci, (name, hist, n_det, kal, P) in enumerate(ASSOC_CASES):
+        tracks, dets, kals = assoc_scene(seed + ci, hist, n_det, kal)
+        if n_det:
+            dists = ref_tracking.center_distance(np.array([t.tlbr * t.scale for t in tracks]), np.array([x.tlbr * x.scale for x in dets]))
+        else:
+            dists = np.zeros((len(tracks), 0))
+        for mode, f64 in (("f64", True), ("f32", False)):
+            set_fake_dtype(model, f64)
+            for sel in (True, False):
+                with torch.no_grad():
+                    pm, rel = model.associate_embeddings(tracks_embeddings=tracks, dets_embeddings=dets, dists_matrix=dists, seq_len=11,
+                                                         num_candidates=P, use_broader_memory=True, select_highest_candidate=sel,
+                                                         extra_kalman_candidates=kals, normalize_ims=True)
+                out["%s_probs_%s_sel%d" % (name, mode, int(sel))] = pm
+                out["%s_reliable" % name] = rel
+        out["%s_dists" % name] = dists
+        print("assoc", name, pm.shape, rel, flush=True)
+    np.savez_compressed(os.path.join(OUT, "assoc.npz"), **out)
+    print("wrote assoc")
+
+
 def main():
     which = set(sys.argv[1:]) or {"dt", "enc", "geom", "assoc", "reid"}
     ref = import_reference()

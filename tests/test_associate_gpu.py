@@ -1,0 +1,98 @@
+"""GPU: the drop-in `BUSCA` class (busca_amd.network, same surface as the reference's busca.network) on fake
+tracker objects, against the committed outputs of the reference's own associate_embeddings."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from busca_amd import synth
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+
+
+def _args(d=64, ff=128, precision="f32", pinned=True):
+    return types.SimpleNamespace(num_layer=4, nhead=4, dim_embedding=512, trans_dim=d, ff_size=ff, activation="gelu",
+                                 dropout_p=0.1, input_flavour="MEM-SEP-CAN-BAD", output_flavour="CAN",
+                                 encode_separator_as_reference=True, encode_special_tokens=False, reid_weights_file="no",
+                                 device=torch.device("cuda:0"), precision=precision, pinned_numpy_semantics=pinned)
+
+
+@pytest.fixture(scope="module")
+def model():
+    from busca_amd.network import BUSCA
+    m = BUSCA(_args()).to(torch.device("cuda:0")).eval()
+    sd = dict(synth.dt_state_dict(17, d=64, ff=128))
+    sd.update({"reid_encoder.model." + k: v for k, v in synth.reid_state_dict(17).items()})
+    m.load_state_dict(sd)
+    return m
+
+
+def _case(ci):
+    import make_golden as mg
+    name, hist, n_det, kal, P = mg.ASSOC_CASES[ci]
+    tracks, dets, kals = mg.assoc_scene(17 + ci, hist, n_det, kal)
+    return name, tracks, dets, kals, P
+
+
+# ReID runs with fp16 operands: the probabilities inherit its ~1e-2 feature tolerance
+PROB_ATOL = 3e-2
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", ["f64", "f32"])
+def test_associate_vs_reference(model, golden_dir, ci, mode):
+    g = np.load(os.path.join(golden_dir, "assoc.npz"))
+    name, tracks, dets, kals, P = _case(ci)
+    model.pinned_numpy = (mode == "f64")
+    model._dirty = True
+    dists = g[name + "_dists"]
+    pm, rel = model.associate_embeddings(tracks_embeddings=tracks, dets_embeddings=dets, dists_matrix=dists, seq_len=11,
+                                         num_candidates=P, use_broader_memory=True, select_highest_candidate=False,
+                                         extra_kalman_candidates=kals, normalize_ims=True)
+    ref = g["%s_probs_%s_sel0" % (name, mode)]
+    assert pm.shape == ref.shape and pm.dtype == np.float64
+    assert np.array_equal(rel, g[name + "_reliable"])
+    assert np.array_equal(pm == 0, ref == 0)                      # same scatter pattern (columns, padding, Kalman slot)
+    assert np.abs(pm - ref).max() <= PROB_ATOL, np.abs(pm - ref).max()
+    # one-hot mode: identical decision wherever the reference's winner is clear of the runner-up
+    pm1, _ = model.associate_embeddings(tracks, dets, dists, 11, P, True, True, extra_kalman_candidates=kals, normalize_ims=True)
+    ref1 = g["%s_probs_%s_sel1" % (name, mode)]
+    assert set(np.unique(pm1)) <= {0.0, 1.0}
+    full = model._last["probs"].cpu().numpy()
+    srt = np.sort(full, axis=-1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2 * PROB_ATOL
+    assert np.array_equal(pm1[clear], ref1[clear])
+
+
+def test_early_returns_and_protocol(model):
+    assert model.associate_embeddings([], [1], None, 11, 5, True, True) == (None, None)
+    assert model.associate_embeddings([1], [], None, 11, 5, True, True, extra_kalman_candidates=[]) == (None, None)
+    assert model.expected_image_size == (384, 128)
+    assert model.num_params > 24_000_000
+    assert model.get_image_crops(np.zeros((64, 64, 3), np.uint8), []).shape == (0, 128, 384, 3)
+    crops = model.get_image_crops(synth.randint_u8(1, "f", (200, 300, 3)), [[10, 10, 60, 150], [-5, -5, 40, 90]], normalize=False)
+    assert crops.shape == (2, 384, 128, 3) and crops.dtype == np.uint8
+    n = model.get_image_crops(synth.randint_u8(1, "f", (200, 300, 3)), [[10, 10, 60, 150]], normalize=True)
+    assert n.dtype == np.float32
+
+
+def test_forward_accepts_reference_float_layout(model):
+    """BUSCA.forward with the reference's normalised float RGB CHW input == the u8 BGR HWC input."""
+    import make_golden as mg
+    from busca_amd import tracking
+    model.pinned_numpy = True
+    model._dirty = True
+    B, L, P = 2, 11, 5
+    mem = mg.smooth_crops(5, B * L).reshape(B, L, 384, 128, 3)
+    can = mg.smooth_crops(6, B * P).reshape(B, P, 384, 128, 3)
+    inp = synth.dt_inputs(5, B, L, P, sentinel_every=0)
+    a = model.forward(mem, can, inp["mem_boxes"], inp["can_boxes"]).cpu().numpy()
+    memf = torch.from_numpy(tracking.normalize_crops(mem)).float()[..., [2, 1, 0]].permute(0, 1, 4, 2, 3)
+    canf = torch.from_numpy(tracking.normalize_crops(can)).float()[..., [2, 1, 0]].permute(0, 1, 4, 2, 3)
+    b = model.forward(memf, canf, inp["mem_boxes"], inp["can_boxes"], return_logits=True, return_att=True).cpu().numpy()
+    assert np.array_equal(a, b)
+    assert model.logits.shape == (B, P + 2, 64) and model.mem_logits.shape == (B, 64) and len(model.attentions) == 4

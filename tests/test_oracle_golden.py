@@ -46,3 +46,141 @@ def test_activation_quirk_is_relu():
     inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)
     gelu = odt.dt_forward(sd, odt.DTConfig(d=d, ff=ff, activation="gelu"), **inp).numpy()
     assert np.abs(gelu - g["logits_f64"]).max() > 1e-3
+
+
+# ---- encoding: LUT rows vs rows of the reference's real 211x211x61xd table, bucket ids in both dtype modes ----
+def test_encoding_luts_match_reference_table(golden_dir):
+    import torch
+    from oracle import encoding as enc
+    g = np.load(os.path.join(golden_dir, "enc.npz"))
+    for d in (12, 64):
+        luts = enc.build_luts(d)
+        idx = g["pe_idx_d%d" % d]
+        rows = enc.encoding_rows(luts, torch.tensor(idx[:, 0]), torch.tensor(idx[:, 1]), torch.tensor(idx[:, 2]), d)
+        ref = g["pe_rows_d%d" % d].view(np.float16).astype(np.float32)
+        assert np.array_equal(rows.numpy(), ref)
+        assert np.array_equal(rows[0].numpy()[:6], np.array([0, 1, 0, 1, 0, 1], np.float32))  # pe[0,0,0] = [0,1,0,1,...]
+
+
+def test_product_luts_equal_oracle_luts():
+    from busca_amd import weights
+    from oracle import encoding as enc
+    for d in (64, 256, 512):
+        lx, ls, lt, c = weights.encoding_luts(d)
+        ox, os_, ot = enc.build_luts(d)
+        assert c == enc.axis_channels(d)
+        assert np.array_equal(lx, ox.numpy().view(np.uint16)) and np.array_equal(ls, os_.numpy().view(np.uint16))
+        assert np.array_equal(lt, ot.numpy().view(np.uint16))
+
+
+@pytest.mark.parametrize("mode", ["f64", "f32"])
+def test_bucket_ids_match_reference(golden_dir, mode):
+    from oracle import encoding as enc
+    g = np.load(os.path.join(golden_dir, "enc.npz"))
+    ids = enc.token_bucket_ids(g["ids_mem_boxes"], g["ids_can_boxes"], fake_f64=(mode == "f64")).numpy()
+    assert np.array_equal(ids, g["ids_" + mode])
+    # the documented sentinel buckets: BAD token and padded candidate
+    bad_xy = ids[0, -1, 0]
+    assert bad_xy == (100 if mode == "f64" else 2)
+
+
+# ---- geometry -----------------------------------------------------------------------------------------
+def test_geometry_matches_reference(golden_dir):
+    from oracle import geometry as og
+    g = np.load(os.path.join(golden_dir, "geom.npz"))
+    assert np.array_equal(og.center_distance(g["a"], g["b"]), g["center"])
+    assert np.array_equal(og.center_distance(g["a"], g["b"], weight_size=True), g["center_w"])
+    # golden sentinels were produced under numpy >= 2 (float32); the pinned flavour differs only in dtype
+    assert np.array_equal(og.missing_candidate_bbox(flavour="ltrb", pinned_numpy=False), g["missing_ltrb"])
+    assert np.array_equal(og.missing_candidate_bbox(flavour="ltwh", pinned_numpy=False), g["missing_ltwh"])
+    assert og.missing_candidate_bbox(flavour="ltwh", pinned_numpy=True).dtype == np.float64
+
+
+def test_track_memory_sampling_matches_reference(golden_dir):
+    from busca_amd.network import memory_indices
+    from oracle.associate import get_track_mem_indices
+    g = np.load(os.path.join(golden_dir, "geom.npz"))
+    for row in g["track_mem"]:
+        n_hist, seq_len, broader = int(row[0]), int(row[1]), bool(row[2])
+        ref = [int(v) for v in row[3:] if v >= 0]
+        assert get_track_mem_indices(n_hist, seq_len, broader) == ref
+        assert memory_indices(n_hist, seq_len, broader) == ref      # the product's host logic, same contract
+
+
+def test_cutout_geometry_matches_reference(golden_dir):
+    from oracle import geometry as og
+    g = np.load(os.path.join(golden_dir, "geom.npz"))
+    fr = synth.randint_u8(3, "frame", (540, 960, 3))
+    for i, bx in enumerate(g["cut_boxes"]):
+        cut = og.cutout_with_pad(fr, bx)
+        assert np.array_equal(np.array(cut.shape), g["cut_shape_%d" % i])
+        assert [int(cut.astype(np.int64).sum()), int(cut[0, 0, 0]), int(cut[-1, -1, 2])] == list(g["cut_sum_%d" % i])
+
+
+def test_resize_known_answers():
+    """OpenCV INTER_LINEAR properties that do not need cv2: constant images stay constant, equal size copies,
+    exact 2x shrink is the rounded 2x2 mean, an upscaled step edge is monotone."""
+    from oracle import geometry as og
+    c = np.full((37, 19, 3), 113, np.uint8)
+    assert (og.resize_linear_u8(c, 128, 384) == 113).all()
+    r = synth.randint_u8(9, "img", (384, 128, 3))
+    assert np.array_equal(og.resize_linear_u8(r, 128, 384), r)
+    big = synth.randint_u8(9, "big", (768, 256, 3)).astype(np.int32)
+    ref = ((big[0::2, 0::2] + big[0::2, 1::2] + big[1::2, 0::2] + big[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(og.resize_linear_u8(big.astype(np.uint8), 128, 384), ref)
+    step = np.zeros((10, 8, 3), np.uint8)
+    step[:, 4:] = 200
+    up = og.resize_linear_u8(step, 128, 384).astype(int)
+    assert (np.diff(up[0, :, 0]) >= 0).all() and up[0, 0, 0] == 0 and up[0, -1, 0] == 200
+
+
+# ---- ReID ---------------------------------------------------------------------------------------------
+def test_reid_oracle_matches_reference(golden_dir):
+    from oracle import reid as oreid
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import smooth_crops
+    g = np.load(os.path.join(golden_dir, "reid.npz"))
+    sd = synth.reid_state_dict(3)
+    crops = smooth_crops(43, 3)
+    got = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
+    np.testing.assert_allclose(got, g["feats_n3_seed43"], rtol=0, atol=2e-5)
+
+
+# ---- associate_embeddings end to end (reference ReID + DT + host logic) ------------------------------------
+def _assoc_case(ci):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    name, hist, n_det, kal, P = mg.ASSOC_CASES[ci]
+    tracks, dets, kals = mg.assoc_scene(17 + ci, hist, n_det, kal)
+    return name, tracks, dets, kals, P
+
+
+@pytest.mark.parametrize("ci", [0, 3])
+def test_associate_oracle_matches_reference(golden_dir, ci):
+    """Oracle ReID + oracle DT + oracle host logic == the reference's associate_embeddings output."""
+    import torch
+    from oracle import associate as oa, reid as oreid
+    g = np.load(os.path.join(golden_dir, "assoc.npz"))
+    name, tracks, dets, kals, P = _assoc_case(ci)
+    seed, d, ff = 17, 64, 128
+    sd_dt, sd_reid = synth.dt_state_dict(seed, d=d, ff=ff), synth.reid_state_dict(seed)
+    cfg = odt.DTConfig(d=d, ff=ff, fake_f64=True)
+
+    def step(mem_u8, can_u8, mem_ltrb, can_ltrb):
+        B, L = mem_u8.shape[:2]
+        P_ = can_u8.shape[1]
+        mf = oreid.reid_forward(sd_reid, oreid.crops_to_reid_input(mem_u8.reshape(B * L, 384, 128, 3))).view(B, L, -1)
+        cf = oreid.reid_forward(sd_reid, oreid.crops_to_reid_input(can_u8.reshape(B * P_, 384, 128, 3))).view(B, P_, -1)
+        return torch.softmax(odt.dt_forward(sd_dt, cfg, mf, cf, mem_ltrb, can_ltrb), -1).numpy()
+
+    pm, rel = oa.associate_embeddings(step, tracks, dets, g[name + "_dists"], 11, P, True, False, extra_kalman_candidates=kals)
+    assert np.array_equal(rel, g[name + "_reliable"])
+    np.testing.assert_allclose(pm, g[name + "_probs_f64_sel0"], rtol=0, atol=5e-5)
+
+
+def test_associate_early_returns():
+    from oracle import associate as oa
+    assert oa.associate_embeddings(None, [], [1], None, 11, 5, True, True) == (None, None)
+    assert oa.associate_embeddings(None, [1], [], None, 11, 5, True, True) == (None, None)
