@@ -161,10 +161,8 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     ev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    from busca_amd import sharding
+    elapsed = sharding.max_over_ranks(elapsed, dist, dev)
 
     # ---- roofline leg: the same launches, each bracketed by HIP events on the launch stream -----------
     lib.busca_timing_enable(h, 1)
