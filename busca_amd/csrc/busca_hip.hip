@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -256,6 +257,27 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
     if (!attr_set) {
         HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LD::TOTAL));
         attr_set = true;
+    }
+    static const bool prof = getenv("BUSCA_DT_PROF") != nullptr;   // debug: phase timestamps of workgroup 0
+    if (prof) {
+        DTParams Q = P;
+        long long* d = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&d, 4 * DT_PROF_SLOTS * sizeof(long long)));
+        HIP_TRY(c, hipMemset(d, 0, 4 * DT_PROF_SLOTS * sizeof(long long)));
+        Q.prof = d;
+        hipLaunchKernelGGL(kern, dim3(P.B), dim3(256), LD::TOTAL, s, Q);
+        HIP_TRY(c, hipStreamSynchronize(s));
+        long long h[4 * DT_PROF_SLOTS];
+        HIP_TRY(c, hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipFree(d));
+        fprintf(stderr, "DT_PROF grid=%d:", P.B);
+        for (int w = 0; w < 4; ++w) {
+            fprintf(stderr, "\n w%d", w);
+            for (int i = 1; i < DT_PROF_SLOTS; ++i)
+                if (h[w * DT_PROF_SLOTS + i]) fprintf(stderr, " %d:%lld", i, h[w * DT_PROF_SLOTS + i] - h[w * DT_PROF_SLOTS]);
+        }
+        fprintf(stderr, "\n");
+        return BUSCA_OK;
     }
     {
         TimedLaunch tl(c, s);
