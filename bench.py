@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py - BUSCA association-step throughput on MI355X (contract in the task statement / DESIGN.md).
+"""bench.py - BUSCA association-step throughput on MI355X (contract in the task statement / DESIGN.md section 5).
 
-One "step" = one pass of the hot path over one frame's batch: B_step lost tracks x P proposals
-(default: the north-star shape 32 x 16, d=256, L=11, 4 layers, 4 heads, ff=512) from ReID features
-that are already resident in HBM to logits/probs/argmax ("DT-step").
-`--inflight F` independent steps (frames of F different sequences sharded onto this GPU) are handed to
-the C-ABI in one call, i.e. one launch processes F steps; F=1 is the single-frame latency case and is
-always measured as `p50_latency_ms`.
+One "step" = one pass of the hot path over one frame's batch: `--lost` lost tracks x `--proposals` proposals
+(default: the north-star shape 32 x 16, d=256, L=11, 4 layers, 4 heads, ff=512) from ReID features that are already
+resident in HBM to logits/probs/argmax ("DT-step", SURVEY.md 8d - the only variant for which >= 10k steps/s is
+physically possible; a full step adds 864 crops x 8 GFLOP of ReID and is reported separately under `full_step`).
+`--inflight F` independent steps (frames of F different sequences sharded onto this GPU) are handed to the C-ABI in
+one call, i.e. one launch processes F steps and fills the 256 CUs; the single-frame case is always measured as
+`p50_latency_ms` (F = 1, one synchronised call per step).
 
     python bench.py                       # 1 GPU, defaults finish in about a minute
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  Primary line = exact-f32 MFMA arithmetic (the reference computes in fp32); the
+f16-operand flavour is reported under `variants`.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -28,7 +31,9 @@ sys.path.insert(0, ROOT)
 
 from busca_amd import synth  # noqa: E402
 
-PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}   # MI355X_MICROARCH.md: f32 MFMA (=vector) peak; dense f16/bf16 MFMA
+# MI355X_MICROARCH.md: f32-input MFMA peak (= f32 vector peak) 157.3 TFLOP/s; dense f16/bf16 MFMA 2500 TFLOP/s
+PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}
+REID_GFLOP_PER_CROP = 8.01          # SURVEY.md 2.1 (4.005 GMAC)
 
 
 def dt_step_flops(B, L, P, d, ff, E=512, nlayers=4):
@@ -81,6 +86,107 @@ def cpu_baseline(sd, cfg_kw, inp, budget_s):
                        % (n, el, best, {k: round(v, 1) for k, v in sweep.items()}))
 
 
+class DTRunner:
+    """F steps worth of synthetic tracks resident in HBM + one loaded Decision-Transformer flavour."""
+
+    def __init__(self, ctx, sd, precision, tens, B, L, P, F, dev):
+        from busca_amd.dt import DecisionTransformerHIP
+        self.ctx, self.B, self.L, self.P, self.F, self.dev = ctx, B, L, P, F, dev
+        self.precision = precision
+        self.model = DecisionTransformerHIP(ctx, sd, activation="relu", fake_bbox_f64=True, precision=precision)
+        self.t = tens
+        self.logits = torch.empty(B * F, P + 2, device=dev)
+        self.probs = torch.empty_like(self.logits)
+        self.amax = torch.empty(B * F, dtype=torch.int32, device=dev)
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def launch(self, nsteps):
+        t, lib = self.t, self.ctx.lib
+        self.ctx.check(lib.busca_dt_forward(self.ctx.h, t["mem_feat"].data_ptr(), t["can_feat"].data_ptr(),
+                                            t["mem_boxes"].data_ptr(), t["can_boxes"].data_ptr(), self.B * nsteps, self.L, self.P,
+                                            self.logits.data_ptr(), self.probs.data_ptr(), self.amax.data_ptr(), None, None, self.stream))
+
+    def run_steps(self, k):
+        full, rem = divmod(k, self.F)
+        for _ in range(full):
+            self.launch(self.F)
+        if rem:
+            self.launch(rem)
+        return full + (1 if rem else 0)
+
+    def kernel_avg_ms(self, k):
+        """Average kernel duration from HIP events recorded around every launch on the launch stream."""
+        lib, h = self.ctx.lib, self.ctx.h
+        lib.busca_timing_read(h, None, None, 1)
+        lib.busca_timing_enable(h, 1)
+        self.run_steps(k)
+        torch.cuda.synchronize(self.dev)
+        avg, n = C.c_double(0), C.c_int64(0)
+        lib.busca_timing_read(h, C.byref(avg), C.byref(n), 1)
+        lib.busca_timing_enable(h, 0)
+        return avg.value, n.value
+
+    def p50_latency_ms(self, samples):
+        if samples <= 0:
+            return None
+        for _ in range(20):
+            self.launch(1)
+        torch.cuda.synchronize(self.dev)
+        lat = []
+        for _ in range(samples):
+            a = time.perf_counter()
+            self.launch(1)
+            torch.cuda.synchronize(self.dev)
+            lat.append(time.perf_counter() - a)
+        return float(np.percentile(np.array(lat), 50) * 1e3)
+
+
+def roofline_obj(precision, B, L, P, d, ff, steps_per_launch, kern_ms, bracket_ms):
+    flops = dt_step_flops(B * steps_per_launch, L, P, d, ff)
+    ach = flops / (kern_ms * 1e-3) / 1e12
+    traffic = None
+    try:    # HBM bytes per launch from the committed PMC run (profiles/pmc_traffic.json), same workload and F
+        meta = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        ent = meta.get("dt_%s_F%d_B%d_P%d_d%d" % (precision, steps_per_launch, B, P, d))
+        traffic = ent["hbm_bytes_per_launch"] if ent else None
+    except Exception:
+        traffic = None
+    return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[precision],
+            "traffic": traffic, "kernel": "dt_fused_kernel", "kernel_avg_ms": kern_ms, "flops_per_launch": flops,
+            "steps_per_launch": steps_per_launch, "event_bracket_ms_per_launch": bracket_ms,
+            "algorithmic_bytes_per_step": dt_step_bytes(B, L, P, d, ff)}
+
+
+def full_step(ctx, dt_model, B, L, P, n_steps, dev):
+    """ReID (two train-mode-BN batches: B*L memory crops, B*P candidate crops, u8 resident in HBM) + DT."""
+    from busca_amd.reid import ReIDEncoderHIP
+    reid = ReIDEncoderHIP(ctx, synth.reid_state_dict(7))
+    mem = torch.from_numpy(synth.randint_u8(11, "mem", (B * L, 384, 128, 3))).to(dev)
+    can = torch.from_numpy(synth.randint_u8(12, "can", (B * P, 384, 128, 3))).to(dev)
+    boxes = synth.dt_inputs(7, B, L, P)
+    mb, cb = torch.from_numpy(boxes["mem_boxes"]).to(dev), torch.from_numpy(boxes["can_boxes"]).to(dev)
+
+    def one():
+        mf = reid.forward(mem).view(B, L, -1)
+        cf = reid.forward(can).view(B, P, -1)
+        return dt_model.forward(mf, cf, mb, cb)
+
+    one()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        one()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / n_steps
+    crops = B * (L + P)
+    tf = crops * REID_GFLOP_PER_CROP * 1e9 / dt / 1e12
+    return {"value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "crops_per_step": crops,
+            "reid_algorithmic_tflop_per_step": crops * REID_GFLOP_PER_CROP / 1e3,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["f16"], "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS["f16"],
+                         "note": "ReID convs (fp16 MFMA, f32 accumulate) + DT over the whole step; u8 crops already in HBM"},
+            "steps": n_steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,19 +196,20 @@ def main():
     ap.add_argument("--proposals", type=int, default=16, help="proposals per track (P)")
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--seq-len", type=int, default=11)
-    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("BUSCA_BENCH_PRECISION", "f16"))
+    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("BUSCA_BENCH_PRECISION", "f32"),
+                    help="MFMA operand type of the primary line; the other one is reported under `variants`")
     ap.add_argument("--inflight", type=int, default=8, help="independent steps handed to one C-ABI call")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--latency-samples", type=int, default=1000)
+    ap.add_argument("--full-steps", type=int, default=6, help="full steps (ReID + DT) timed for `full_step` (0 = skip)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary-precision / full-step measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0 and world > 1:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-        args.gpus = world
+    if world != args.gpus and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -111,105 +218,76 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from busca_amd import _lib
-    from busca_amd.dt import DecisionTransformerHIP
+    from busca_amd import _lib, sharding
 
     B, P, L, d, ff, F = args.lost, args.proposals, args.seq_len, args.d, 2 * args.d, max(1, args.inflight)
     seed = 7   # the reference configs' tracker.seed (config/*/*/*.yml:18)
     sd = synth.dt_state_dict(seed, d=d, ff=ff)
     ctx = _lib.Context(local_rank)
-    model = DecisionTransformerHIP(ctx, sd, activation="relu", fake_bbox_f64=True, precision=args.precision)
-
     # synthetic inputs resident in HBM before the timed region: F steps worth of tracks, each rank its own seed
     big = synth.dt_inputs(seed + 1000 * rank, B * F, L, P)
     tens = {k: torch.from_numpy(v).to(dev) for k, v in big.items()}
-    n_out = P + 2
-    logits = torch.empty(B * F, n_out, device=dev)
-    probs = torch.empty_like(logits)
-    amax = torch.empty(B * F, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    lib, h = ctx.lib, ctx.h
-
-    def launch(nsteps):
-        nb = B * nsteps
-        ctx.check(lib.busca_dt_forward(h, tens["mem_feat"].data_ptr(), tens["can_feat"].data_ptr(),
-                                       tens["mem_boxes"].data_ptr(), tens["can_boxes"].data_ptr(), nb, L, P,
-                                       logits.data_ptr(), probs.data_ptr(), amax.data_ptr(), None, None, stream))
-
-    def run_steps(k):
-        full, rem = divmod(k, F)
-        for _ in range(full):
-            launch(F)
-        if rem:
-            launch(rem)
-        return full + (1 if rem else 0)
+    run = DTRunner(ctx, sd, args.precision, tens, B, L, P, F, dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- warm-up, then EXACTLY K steps between barriers -----------------------------------------------
-    run_steps(args.warmup)
+    # ---- warm-up, then EXACTLY K steps between barriers ---------------------------------------------------------
+    run.run_steps(args.warmup)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    n_launch = run_steps(args.steps)
+    n_launch = run.run_steps(args.steps)
     ev1.record()
     barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    from busca_amd import sharding
     elapsed = sharding.max_over_ranks(elapsed, dist, dev)
 
-    # ---- roofline leg: the same launches, each bracketed by HIP events on the launch stream -----------
-    lib.busca_timing_enable(h, 1)
-    run_steps(min(args.steps, 50 * F))
-    torch.cuda.synchronize(dev)
-    import ctypes as C
-    avg_ms, nl = C.c_double(0), C.c_int64(0)
-    lib.busca_timing_read(h, C.byref(avg_ms), C.byref(nl), 1)
-    lib.busca_timing_enable(h, 0)
-    steps_per_launch = F if args.steps >= F else args.steps
-    flops_launch = dt_step_flops(B * steps_per_launch, L, P, d, ff)
-    kern_ms = avg_ms.value if nl.value else ev_ms / max(1, n_launch)
-    achieved_tf = flops_launch / (kern_ms * 1e-3) / 1e12
-    peak = PEAK_TFLOPS[args.precision]
-
-    # ---- single-step latency (F=1), host-timed, stream-synchronised -----------------------------------
-    lat = []
-    for _ in range(20):
-        launch(1)
-    torch.cuda.synchronize(dev)
-    for _ in range(args.latency_samples):
-        a = time.perf_counter()
-        launch(1)
-        torch.cuda.synchronize(dev)
-        lat.append(time.perf_counter() - a)
-    p50 = float(np.percentile(np.array(lat), 50) * 1e3) if lat else None
+    # ---- roofline leg: the same launches, each bracketed by HIP events on the launch stream -------------------
+    spl = F if args.steps >= F else args.steps
+    kern_ms, nl = run.kernel_avg_ms(min(args.steps, 50 * F))
+    if not nl:
+        kern_ms = ev_ms / max(1, n_launch)
+    p50 = run.p50_latency_ms(args.latency_samples)
 
     result = None
     if rank == 0:
         total_steps = args.steps * world
-        value = total_steps / elapsed
         result = {
             "metric": "BUSCA association steps/sec (DT-step: features in HBM -> logits/probs/argmax), MOT17-like %d lost x %d proposals" % (B, P),
-            "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": total_steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "p50_latency_ms": p50,
-            "config": {"workload": "cfgN DT-step: %d lost x %d proposals x d%d (L=%d, T=%d, ff=%d, 4 layers, 4 heads), "
-                                   "ReID features precomputed; BASELINE.json configs[1]-shaped batch without the tracker" % (B, P, d, L, L + 2 * (P + 2), ff),
+            "config": {"workload": "cfgN DT-step: %d lost x %d proposals x d%d (L=%d, T=%d, ff=%d, 4 layers, 4 heads), ReID features "
+                                   "precomputed; BASELINE.json configs[1]-shaped batch without the tracker" % (B, P, d, L, L + 2 * (P + 2), ff),
                        "lost": B, "proposals": P, "d": d, "seq_len": L, "steps_in_flight_per_launch": F,
                        "parallelism": "independent sequences sharded per GPU, no collective (%d rank%s)" % (world, "" if world == 1 else "s")},
-            "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
-                         "traffic": None, "kernel": "dt_fused_kernel", "kernel_avg_ms": kern_ms,
-                         "flops_per_launch": flops_launch, "steps_per_launch": steps_per_launch,
-                         "event_bracket_ms_per_launch": ev_ms / max(1, n_launch),
-                         "algorithmic_bytes_per_step": dt_step_bytes(B, L, P, d, ff)},
+            "roofline": roofline_obj(args.precision, B, L, P, d, ff, spl, kern_ms, ev_ms / max(1, n_launch)),
         }
+    # ---- secondary precision + full step (rank 0, outside the contract's timed region) ---------------------------
+    if rank == 0 and not args.no_variants:
+        other = "f16" if args.precision == "f32" else "f32"
+        r2 = DTRunner(ctx, sd, other, tens, B, L, P, F, dev)
+        k2 = min(args.steps, 2000)
+        r2.run_steps(min(args.warmup, 200))
+        torch.cuda.synchronize(dev)
+        a = time.perf_counter()
+        nl2 = r2.run_steps(k2)
+        torch.cuda.synchronize(dev)
+        el2 = time.perf_counter() - a
+        km2, n2 = r2.kernel_avg_ms(min(k2, 50 * F))
+        result["variants"] = {other: {"value": k2 / el2, "unit": "steps/s", "steps": k2, "n_gpus": 1, "dtype": other,
+                                      "p50_latency_ms": r2.p50_latency_ms(min(args.latency_samples, 300)),
+                                      "roofline": roofline_obj(other, B, L, P, d, ff, min(F, k2), km2 if n2 else el2 / nl2 * 1e3, el2 / nl2 * 1e3)}}
+        if args.full_steps > 0:
+            f16_model = r2.model if other == "f16" else DTRunner(ctx, sd, "f16", tens, B, L, P, 1, dev).model
+            result["full_step"] = full_step(ctx, f16_model, B, L, P, args.full_steps, dev)
+    if rank == 0:
         if args.cpu_seconds > 0:
             one = {k: v[:B] for k, v in big.items()}
             result["cpu_baseline"] = cpu_baseline(sd, dict(d=d, ff=ff), one, args.cpu_seconds)

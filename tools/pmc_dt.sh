@@ -2,7 +2,7 @@
 # PMC passes for the fused DT kernel (run on the GPU box through gpurun). Usage: tools/pmc_dt.sh <f16|f32> <outdir>
 export TMPDIR=/tmp
 P=$1; OUT=$2; mkdir -p $OUT
-CMD="python3 bench.py --precision $P --cpu-seconds 0 --steps 80 --warmup 8 --latency-samples 0"
+CMD="python3 bench.py --precision $P --cpu-seconds 0 --steps 80 --warmup 8 --latency-samples 0 --no-variants"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $OUT -o p1 -- $CMD > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT -o p2 -- $CMD > $OUT/p2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE TCC_HIT --kernel-trace --output-format csv -d $OUT -o p3 -- $CMD > $OUT/p3.log 2>&1
