@@ -240,7 +240,8 @@ class BUSCA:
             v = np.rint((img.astype(np.float64) * tracking._PIXEL_STD + tracking._PIXEL_MEAN) * 255.0)
             return np.clip(v, 0, 255).astype(np.uint8)
 
-        mem_u8 = np.zeros((B, L, H, W, 3), np.uint8)
+        # crops are collected as references; zero crops are None (incomplete memory, padded candidate)
+        mem_ref = [[None] * L for _ in range(B)]
         mem_box = np.empty((B, L, 4), np.float64)
         reliable = np.zeros(B, bool)
         for t, trk in enumerate(tracks_embeddings):
@@ -248,7 +249,7 @@ class BUSCA:
             idx = memory_indices(len(hist), L, use_broader_memory)
             if len(idx) == L:
                 for j, i in enumerate(idx):
-                    mem_u8[t, j] = as_u8(hist[i])
+                    mem_ref[t][j] = hist[i]
                     mem_box[t, j] = np.asarray(trk.tlwh_mem[i], dtype=np.float64) * trk.scale
                 reliable[t] = True
             else:                               # incomplete memory: zero crops, dummy box, flagged unreliable
@@ -260,20 +261,18 @@ class BUSCA:
             d = np.ascontiguousarray(np.asarray(dists_matrix, dtype=np.float64).reshape(B, N))
             order = geometry.topk_rows(self._ctx, d, P).cpu().numpy().astype(np.int64)
         miss = tracking.missing_candidate_bbox(flavour="ltwh", pinned_numpy=self.pinned_numpy).astype(np.float64)
-        can_u8 = np.zeros((B, P, H, W, 3), np.uint8)
+        can_ref = [[None] * P for _ in range(B)]
         can_box = np.empty((B, P, 4), np.float64)
         can_box[:] = miss
-        det_img = [None] * N
         det_box = np.empty((N, 4), np.float64)
         for di in np.unique(order[order >= 0]):
             det = dets_embeddings[di]
-            det_img[di] = as_u8(det.images_mem[-1])
             det_box[di] = np.asarray(det.tlwh_mem[-1], dtype=np.float64) * det.scale
         for t in range(B):
             for j in range(P):
                 di = order[t, j]
                 if di >= 0:
-                    can_u8[t, j] = det_img[di]
+                    can_ref[t][j] = dets_embeddings[di].images_mem[-1]
                     can_box[t, j] = det_box[di]
         n_avail = min(N, P)
         if K > 0:                               # the track's own Kalman prediction takes slot min(N, P-1)
@@ -283,7 +282,7 @@ class BUSCA:
                 kd = extra_kalman_candidates[t]
                 order[t, slot] = N + t
                 can_box[t, slot] = np.asarray(kd.tlwh, dtype=np.float64) * kd.scale
-                can_u8[t, slot] = as_u8(kd.images_mem[-1])
+                can_ref[t][slot] = kd.images_mem[-1]
 
         with np.errstate(over="ignore"):
             mem_ltrb = mem_box.astype(np.float32)
@@ -291,9 +290,8 @@ class BUSCA:
             mem_ltrb[..., 2:] += mem_ltrb[..., :2]
             can_ltrb[..., 2:] += can_ltrb[..., :2]
 
-        dev = self._dev()
-        mem_feat = self._reid.forward(torch.from_numpy(mem_u8.reshape(B * L, H, W, 3)).to(dev)).view(B, L, -1)
-        can_feat = self._reid.forward(torch.from_numpy(can_u8.reshape(B * P, H, W, 3)).to(dev)).view(B, P, -1)
+        mem_feat = self._reid.forward(self._gather_crops(mem_ref, as_u8)).view(B, L, -1)   # BN batch 1
+        can_feat = self._reid.forward(self._gather_crops(can_ref, as_u8)).view(B, P, -1)   # BN batch 2
         out = self._dt.forward(mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=self.store_logits)
         self._last = out
         if self.store_logits:
@@ -316,6 +314,25 @@ class BUSCA:
         for t in range(B):
             probs_matrix[t, order[t, :n_avail]] = probs[t, :n_avail]
         return probs_matrix, reliable
+
+    def _gather_crops(self, refs, as_u8):
+        """[B][n] crop references (None = all-zero crop) -> cuda u8 [B*n,384,128,3].  Crops that still carry their
+        device twin (tracking.DeviceBackedCrops) are gathered on the GPU; the rest go through one host batch."""
+        dev = self._dev()
+        H, W = self.expected_image_size
+        flat = [r for row in refs for r in row]
+        out = torch.zeros(len(flat), H, W, 3, dtype=torch.uint8, device=dev)
+        on_dev = [(i, r.dev) for i, r in enumerate(flat)
+                  if r is not None and getattr(r, "dev", None) is not None and r.dev.device == dev]
+        taken = {i for i, _ in on_dev}
+        on_host = [(i, r) for i, r in enumerate(flat) if r is not None and i not in taken]
+        if on_dev:
+            out[torch.tensor([i for i, _ in on_dev], device=dev)] = torch.stack([d for _, d in on_dev])
+        if on_host:
+            host = np.stack([as_u8(r) for _, r in on_host])
+            out[torch.tensor([i for i, _ in on_host], device=dev)] = torch.from_numpy(host).to(dev)
+        self.last_gather = (len(on_dev), len(on_host))       # (device-resident, host) crops of the last call
+        return out
 
     # ---- helpers with the reference's names ------------------------------------------------------------------
     def _get_track_mem(self, track, seq_len, use_broader_memory):

@@ -65,6 +65,30 @@ def normalize_crops(u8):
     return x
 
 
+class DeviceBackedCrops(np.ndarray):
+    """Host uint8 crops that remember their device-resident twin (device-resident track memory).
+
+    `get_image_crops(..., normalize=False)` returns this ndarray subclass: to the trackers it is an ordinary
+    uint8 array ([N,384,128,3]; `crops[i]` is what they append to `images_mem`), but every view also carries
+    `.dev`, the matching slice of the CUDA tensor the crop kernel wrote.  `associate_embeddings` gathers the
+    `.dev` views on the GPU and skips the per-frame host->device copy of B*(L+P) crops (147 KB each); crops
+    that lost their twin (np.array(...) copies, other sources) silently take the host path."""
+
+    def __new__(cls, host, dev):
+        obj = np.asarray(host).view(cls)
+        obj.dev = dev
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.dev = None                     # generic views/copies do not know which device rows they cover
+
+    def __getitem__(self, key):
+        out = super().__getitem__(key)
+        if isinstance(out, DeviceBackedCrops) and self.dev is not None and self.ndim == 4 and isinstance(key, (int, np.integer)):
+            out.dev = self.dev[int(key)]
+        return out
+
+
 def get_image_crops(im, bboxes, normalize=True, ctx=None):
     """All crops of one frame in one launch: u8 BGR [N,384,128,3] (float32 normalised if `normalize`)."""
     bboxes = np.asarray(bboxes, dtype=np.float32).reshape(-1, 4)
@@ -73,7 +97,9 @@ def get_image_crops(im, bboxes, normalize=True, ctx=None):
     ctx = ctx or geometry.default_context()
     u8, _ = geometry.crop_gather(ctx, im, bboxes, want_u8=True)
     crops = u8.cpu().numpy()
-    return normalize_crops(crops) if normalize else crops
+    if normalize:
+        return normalize_crops(crops)
+    return DeviceBackedCrops(crops, u8)
 
 
 def get_bbox_crop(im, bbox_real_scale, output_size=(128, 384), normalize=True, ghost_normalize=True, ctx=None):

@@ -96,3 +96,29 @@ def test_forward_accepts_reference_float_layout(model):
     b = model.forward(memf, canf, inp["mem_boxes"], inp["can_boxes"], return_logits=True, return_att=True).cpu().numpy()
     assert np.array_equal(a, b)
     assert model.logits.shape == (B, P + 2, 64) and model.mem_logits.shape == (B, 64) and len(model.attentions) == 4
+
+
+def test_device_resident_track_memory(model):
+    """Crops returned by get_image_crops keep a device twin; association then gathers them on the GPU
+    (no H2D) and gives bit-identical results to the host path."""
+    from busca_amd.tracking import DeviceBackedCrops
+    import make_golden as mg
+    model.pinned_numpy = True
+    model._dirty = True
+    frame = synth.randint_u8(4, "frame", (540, 960, 3))
+    boxes = np.array([[50 + 30 * i, 40 + 5 * i, 110 + 30 * i, 260 + 5 * i] for i in range(24)], np.float32)
+    crops = model.get_image_crops(frame, boxes, normalize=False)
+    assert isinstance(crops, DeviceBackedCrops) and crops.dev is not None and crops[3].dev is not None
+    assert np.array_equal(crops[3].dev.cpu().numpy(), np.asarray(crops[3]))
+    hist = [mg.FakeTrack([[50, 40, 60, 220]] * 12, [crops[i] for i in range(12)]), mg.FakeTrack([[300, 80, 60, 220]] * 11, [crops[i] for i in range(12, 23)])]
+    dets = [mg.FakeTrack([[55, 45, 60, 220]], [crops[23]]), mg.FakeTrack([[310, 85, 60, 220]], [crops[5]])]
+    kal = [mg.FakeTrack([[52, 42, 60, 220]], [crops[1]]), mg.FakeTrack([[305, 82, 60, 220]], [crops[14]])]
+    dists = np.array([[7.0, 250.0], [250.0, 11.0]])
+    a, ra = model.associate_embeddings(hist, dets, dists, 11, 5, True, False, extra_kalman_candidates=kal, normalize_ims=True)
+    assert model.last_gather[1] == 0 and model.last_gather[0] > 0           # everything came from the device pool
+    # same scene with plain host copies of the crops -> host path
+    plain = lambda trk: mg.FakeTrack(trk.tlwh_mem, [np.array(c) for c in trk.images_mem], trk.scale)
+    b, rb = model.associate_embeddings([plain(t) for t in hist], [plain(t) for t in dets], dists, 11, 5, True, False,
+                                       extra_kalman_candidates=[plain(t) for t in kal], normalize_ims=True)
+    assert model.last_gather[0] == 0 and model.last_gather[1] > 0
+    assert np.array_equal(a, b) and np.array_equal(ra, rb)
