@@ -18,14 +18,23 @@
 #include "pairwise_kernel.hip.inc"
 #include "crop_kernel.hip.inc"
 #include "reid_kernel.hip.inc"
+#include "dt_tiled.hip.inc"
 
 // ---------------------------------------------------------------------------------------------------------
+struct DTTiledW {                   // row-major f16 copies of the matrices for the tiled path (f16 precision only)
+    const _Float16* w_embed = nullptr;
+    const _Float16 *w_in[DT_MAX_LAYERS] = {}, *w_out[DT_MAX_LAYERS] = {}, *w1[DT_MAX_LAYERS] = {}, *w2[DT_MAX_LAYERS] = {};
+};
+
 struct DTState {
     bool loaded = false;
     busca_dt_cfg cfg{};
     void* dev_blob = nullptr;      // one allocation holding every packed matrix / vector / LUT
     size_t dev_bytes = 0;
     DTParams proto{};              // weight pointers filled in, per-call fields zero
+    void* dev_tiled = nullptr;     // row-major f16 matrices (tiled path)
+    DTTiledW tw;
+    void* ws = nullptr; size_t ws_bytes = 0;   // tiled-path activation workspace
 };
 
 struct busca_ctx {
@@ -100,6 +109,8 @@ extern "C" void busca_ctx_destroy(busca_ctx* c) {
     timing_drain(c);
     for (auto e : c->ev_free) hipEventDestroy(e);
     if (c->dt.dev_blob) hipFree(c->dt.dev_blob);
+    if (c->dt.dev_tiled) hipFree(c->dt.dev_tiled);
+    if (c->dt.ws) hipFree(c->dt.ws);
     if (c->crop_fill) hipFree(c->crop_fill);
     reid_free(c->reid);
     delete c;
@@ -243,6 +254,26 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
     P.nlayers = g->nlayers; P.act = g->activation; P.fake_f64 = g->fake_bbox_f64;
     S.proto = P;
     S.cfg = *g;
+    if (S.dev_tiled) { HIP_TRY(c, hipFree(S.dev_tiled)); S.dev_tiled = nullptr; }
+    S.tw = DTTiledW();
+    if (prec == BUSCA_PREC_F16) {   // plain row-major f16 matrices for the tiled (layer-wise) path
+        std::vector<_Float16> hw;
+        auto put16 = [&](const float* src, size_t n) { while (hw.size() % 8) hw.push_back((_Float16)0.f); size_t off = hw.size(); for (size_t i = 0; i < n; ++i) hw.push_back((_Float16)src[i]); return off; };
+        const float* q = blob;
+        const size_t o_e = put16(q, (size_t)d * E); q += (size_t)d * E + d + 3 * d;
+        size_t oi[DT_MAX_LAYERS], oo[DT_MAX_LAYERS], o1[DT_MAX_LAYERS], o2[DT_MAX_LAYERS];
+        for (int l = 0; l < g->nlayers; ++l) {
+            oi[l] = put16(q, (size_t)3 * d * d); q += (size_t)3 * d * d + 3 * d;
+            oo[l] = put16(q, (size_t)d * d); q += (size_t)d * d + d;
+            o1[l] = put16(q, (size_t)ff * d); q += (size_t)ff * d + ff;
+            o2[l] = put16(q, (size_t)d * ff); q += (size_t)d * ff + d + 4 * d;
+        }
+        HIP_TRY(c, hipMalloc(&S.dev_tiled, hw.size() * sizeof(_Float16)));
+        HIP_TRY(c, hipMemcpy(S.dev_tiled, hw.data(), hw.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+        const _Float16* tb = (const _Float16*)S.dev_tiled;
+        S.tw.w_embed = tb + o_e;
+        for (int l = 0; l < g->nlayers; ++l) { S.tw.w_in[l] = tb + oi[l]; S.tw.w_out[l] = tb + oo[l]; S.tw.w1[l] = tb + o1[l]; S.tw.w2[l] = tb + o2[l]; }
+    }
     S.loaded = true;
     return BUSCA_OK;
 }
@@ -287,6 +318,97 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
     return BUSCA_OK;
 }
 
+// ---- tiled (layer-wise) path ---------------------------------------------------------------------------------------
+template <int D, int EPI>
+static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblocks) {
+    const size_t lds = (size_t)(64 + D) * 128 + 2 * 4 * 64 * sizeof(float);
+    auto kern = dtl_gemm_kernel<D, EPI>;
+    static bool attr = false;
+    if (!attr) { HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    TimedLaunch tl(c, s);
+    hipLaunchKernelGGL(kern, dim3((a.M + 63) / 64, ncolblocks), dim3(256), lds, s, a);
+    return BUSCA_OK;
+}
+
+template <int D, int MT>
+static int dtl_attention(busca_ctx* c, hipStream_t s, const _Float16* qkv, _Float16* O, int B, int T, float* att) {
+    constexpr int HD = D / 4, NCK = (MT + 1) / 2;
+    const size_t lds = (size_t)16 * MT * (HD * 2 + 16) + (size_t)HD * (32 * NCK * 2 + 16);
+    auto kern = dtl_attention_kernel<D, MT>;
+    static bool attr = false;
+    if (!attr) { HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    TimedLaunch tl(c, s);
+    hipLaunchKernelGGL(kern, dim3(B, 4), dim3(256), lds, s, qkv, O, T, att);
+    return BUSCA_OK;
+}
+
+template <int D>
+static int dtl_attention_mt(busca_ctx* c, hipStream_t s, int MT, const _Float16* qkv, _Float16* O, int B, int T, float* att) {
+    switch (MT) {
+        case 1: return dtl_attention<D, 1>(c, s, qkv, O, B, T, att);
+        case 2: return dtl_attention<D, 2>(c, s, qkv, O, B, T, att);
+        case 3: return dtl_attention<D, 3>(c, s, qkv, O, B, T, att);
+        case 4: return dtl_attention<D, 4>(c, s, qkv, O, B, T, att);
+        case 5: return dtl_attention<D, 5>(c, s, qkv, O, B, T, att);
+        case 6: return dtl_attention<D, 6>(c, s, qkv, O, B, T, att);
+        case 7: return dtl_attention<D, 7>(c, s, qkv, O, B, T, att);
+        case 8: return dtl_attention<D, 8>(c, s, qkv, O, B, T, att);
+        case 9: return dtl_attention<D, 9>(c, s, qkv, O, B, T, att);
+    }
+    return fail(c, BUSCA_EINVAL, "tiled attention supports at most 144 tokens per track (got %d)", T);
+}
+
+template <int D>
+static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
+    DTState& S = c->dt;
+    const int T = K.T, B = K.B, L = K.L, P = K.P, FF = 2 * D, E = 512;
+    const int MT = (T + 15) / 16;
+    if (MT > 9) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most 144 tokens per track (T=%d)", T);
+    if (P + 2 > 128) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most 126 proposals (P=%d)", P);
+    const size_t M = (size_t)B * T;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t need = al(M * D * 4) + al(M * D * 2) + al(M * 3 * D * 2) + al(M * D * 2) + al(M * FF * 2) + al(M * 3 * 4);
+    if (S.ws_bytes < need) {
+        if (S.ws) { HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(S.ws)); S.ws = nullptr; S.ws_bytes = 0; }
+        if (hipMalloc(&S.ws, need) != hipSuccess) return fail(c, BUSCA_ENOMEM, "cannot allocate %zu bytes of DT workspace", need);
+        S.ws_bytes = need;
+    }
+    char* p = (char*)S.ws;
+    float* X = (float*)p; p += al(M * D * 4);
+    _Float16* Xh = (_Float16*)p; p += al(M * D * 2);
+    _Float16* QKV = (_Float16*)p; p += al(M * 3 * D * 2);
+    _Float16* O = (_Float16*)p; p += al(M * D * 2);
+    _Float16* H = (_Float16*)p; p += al(M * FF * 2);
+    int* ids = (int*)p;
+    hipLaunchKernelGGL(dt_bucket_ids_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, K.mem_ltrb, K.can_ltrb, B, L, P, K.fake_f64, ids);
+    DTLArgs a{};
+    a.M = (int)M; a.L = L; a.P = P; a.T = T; a.E = E; a.X = X; a.Xh = Xh; a.act = K.act;
+    a.qscale = 1.0f / sqrtf((float)(D / 4));
+    // embed + assembly + encoding
+    a.W = S.tw.w_embed; a.K = E; a.bias = K.b_embed; a.mem_feat = K.mem_feat; a.can_feat = K.can_feat; a.ids = ids;
+    a.lut_xy = K.lut_xy; a.lut_sz = K.lut_sz; a.lut_t = K.lut_t; a.lut_c = K.lut_c;
+    a.tok_sep = K.tok_sep; a.tok_non = K.tok_non; a.tok_bad = K.tok_bad;
+    { int rc = dtl_gemm<D, DTL_EPI_EMBED>(c, s, a, 1); if (rc) return rc; }
+    for (int l = 0; l < K.nlayers; ++l) {
+        const DTLayerW& W = K.layer[l];
+        a.A = Xh; a.lda = D; a.W = S.tw.w_in[l]; a.K = D; a.bias = W.b_in; a.out16 = QKV; a.ldo = 3 * D;
+        { int rc = dtl_gemm<D, DTL_EPI_QKV>(c, s, a, 3); if (rc) return rc; }
+        float* att = K.att ? K.att + (size_t)l * B * 4 * T * T : nullptr;
+        { int rc = dtl_attention_mt<D>(c, s, MT, QKV, O, B, T, att); if (rc) return rc; }
+        a.A = O; a.lda = D; a.W = S.tw.w_out[l]; a.K = D; a.bias = W.b_out; a.gamma = W.g1; a.beta = W.be1;
+        { int rc = dtl_gemm<D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
+        a.A = Xh; a.lda = D; a.W = S.tw.w1[l]; a.K = D; a.bias = W.b1; a.out16 = H; a.ldo = FF;
+        { int rc = dtl_gemm<D, DTL_EPI_FFN1>(c, s, a, FF / D); if (rc) return rc; }
+        a.A = H; a.lda = FF; a.W = S.tw.w2[l]; a.K = FF; a.bias = W.b2; a.gamma = W.g2; a.beta = W.be2;
+        { int rc = dtl_gemm<D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
+    }
+    if (K.hidden) HIP_TRY(c, hipMemcpyAsync(K.hidden, X, M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL((dtl_decoder_kernel<D>), dim3(B), dim3(256), 0, s, (const float*)X, T, L, P, K.dec_g, K.dec_b, K.dec_w, K.dec_bias,
+                       K.logits, K.probs, K.argmax);
+    HIP_TRY(c, hipGetLastError());
+    return BUSCA_OK;
+}
+
 extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
                                 const float* can_ltrb, int32_t B, int32_t L, int32_t P, float* logits, float* probs,
                                 int32_t* argmax, float* hidden, float* att, void* stream) {
@@ -295,7 +417,6 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     if (B < 0 || L < 1 || P < 1 || !logits) return fail(c, BUSCA_EINVAL, "bad shape B=%d L=%d P=%d or null logits", B, L, P);
     if (B == 0) return BUSCA_OK;
     if (!mem_feat || !can_feat || !mem_ltrb || !can_ltrb) return fail(c, BUSCA_EINVAL, "null input pointer");
-    if (P + 2 > 64) return fail(c, BUSCA_EINVAL, "P=%d: the fused path supports at most 62 proposals per track", P);
     DTParams K = c->dt.proto;
     K.mem_feat = mem_feat; K.can_feat = can_feat; K.mem_ltrb = mem_ltrb; K.can_ltrb = can_ltrb;
     K.logits = logits; K.probs = probs; K.argmax = argmax; K.hidden = hidden; K.att = att;
@@ -303,7 +424,9 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     const int MT = (K.T + 15) / 16;
     const int d = c->dt.cfg.d, prec = c->dt.cfg.precision;
     hipStream_t s = (hipStream_t)stream;
-#define DT_CASE(PR, M, DD, NCH) if (prec == PR && MT == M && d == DD) return dt_launch<PR, M, DD, 2 * DD, NCH>(c, K, s)
+    const bool force_tiled = getenv("BUSCA_DT_TILED") != nullptr;          // testing: run the layer-wise path on any shape
+    const bool fused_ok = !force_tiled && P + 2 <= 64;
+#define DT_CASE(PR, M, DD, NCH) if (fused_ok && prec == PR && MT == M && d == DD) return dt_launch<PR, M, DD, 2 * DD, NCH>(c, K, s)
     DT_CASE(0, 1, 64, 1); DT_CASE(0, 1, 256, 1); DT_CASE(0, 1, 512, 1); DT_CASE(1, 1, 64, 1); DT_CASE(1, 1, 256, 1); DT_CASE(1, 1, 512, 1);
     DT_CASE(0, 2, 64, 1); DT_CASE(0, 3, 64, 1); DT_CASE(0, 4, 64, 1);
     DT_CASE(0, 2, 256, 1); DT_CASE(0, 3, 256, 1);
@@ -312,7 +435,13 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     DT_CASE(1, 2, 256, 1); DT_CASE(1, 3, 256, 1); DT_CASE(1, 4, 256, 1); DT_CASE(1, 5, 256, 1);
     DT_CASE(1, 2, 512, 1); DT_CASE(1, 3, 512, 1); DT_CASE(1, 4, 512, 2);
 #undef DT_CASE
-    return fail(c, BUSCA_EINVAL, "no fused DT kernel for T=%d (tiles %d), d=%d, precision=%d", K.T, MT, d, prec);
+    if (prec == BUSCA_PREC_F16) {          // shapes beyond the fused kernel's on-chip plan: layer-wise tiled path
+        if (d == 64) return dt_forward_tiled<64>(c, K, s);
+        if (d == 256) return dt_forward_tiled<256>(c, K, s);
+        if (d == 512) return dt_forward_tiled<512>(c, K, s);
+    }
+    return fail(c, BUSCA_EINVAL, "no f32 Decision-Transformer kernel for T=%d (tiles %d), d=%d: the fused f32 path holds T<=48 (d<=256) "
+                                 "or T<=32 (d=512); use precision f16 for larger shapes", K.T, MT, d);
 }
 
 extern "C" int busca_dt_bucket_ids(busca_ctx* c, const float* mem_ltrb, const float* can_ltrb, int32_t B, int32_t L,

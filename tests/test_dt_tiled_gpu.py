@@ -1,0 +1,88 @@
+"""GPU parity of the tiled (layer-wise) Decision-Transformer path: forced on the golden shapes, and on the shapes
+only it can run (BASELINE configs 3 and 4: 128 x 32 -> T = 79 and 64 proposals x d512 -> T = 143)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from busca_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dt_*.npz")))
+TOL = dict(logit=6e-2, prob=5e-3, att=5e-3, hidden=8e-2, margin=2e-2)     # f16-operand tolerances (as test_dt_gpu.py)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from busca_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture()
+def force_tiled():
+    os.environ["BUSCA_DT_TILED"] = "1"
+    yield
+    os.environ.pop("BUSCA_DT_TILED", None)
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+@pytest.mark.parametrize("mode", ["f64", "f32"])
+def test_tiled_vs_reference_golden(ctx, force_tiled, path, mode):
+    from busca_amd.dt import DecisionTransformerHIP
+    g = np.load(path)
+    d, ff, B, L, P, seed = (int(g[k]) for k in ("d", "ff", "B", "L", "P", "seed"))
+    sd = synth.dt_state_dict(seed, d=d, ff=ff)
+    inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4 if B <= 8 else 16)
+    has_att = ("att_" + mode) in g
+    m = DecisionTransformerHIP(ctx, sd, fake_bbox_f64=(mode == "f64"), precision="f16")
+    out = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"], want_hidden=True, want_att=has_att)
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    assert np.abs(out["logits"] - g["logits_" + mode]).max() <= TOL["logit"]
+    assert np.abs(out["probs"] - g["probs_" + mode]).max() <= TOL["prob"]
+    pos = [L + 2 * j + 1 for j in range(P + 2)]
+    assert np.abs(out["hidden"][:, pos] - g["can_hidden_" + mode]).max() <= TOL["hidden"]
+    if has_att:
+        assert np.abs(out["att"] - g["att_" + mode]).max() <= TOL["att"]
+    ref_p = g["probs_" + mode]
+    srt = np.sort(ref_p, axis=-1)
+    clear = (srt[:, -1] - srt[:, -2]) > TOL["margin"]
+    assert (out["argmax"][clear] == g["argmax_" + mode][clear]).all()
+    assert (out["argmax"] == out["probs"].argmax(-1)).all()
+
+
+@pytest.mark.parametrize("shape", [(128, 11, 32, 512), (24, 11, 64, 512), (40, 11, 40, 256), (9, 11, 62, 64)],
+                         ids=["cfg4_128x32_d512", "cfg5_shape_x64_d512", "T95_d256", "T139_d64"])
+def test_tiled_large_shapes_vs_oracle(ctx, shape):
+    """Shapes the fused kernel cannot hold (dispatch picks the tiled path by itself)."""
+    from busca_amd.dt import DecisionTransformerHIP
+    from oracle import dt as odt
+    B, L, P, d = shape
+    seed = 300 + P + d
+    sd = synth.dt_state_dict(seed, d=d, ff=2 * d)
+    inp = synth.dt_inputs(seed, B, L, P, sentinel_every=8)
+    m = DecisionTransformerHIP(ctx, sd, precision="f16")
+    out = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    ref = odt.dt_forward(sd, odt.DTConfig(d=d, ff=2 * d), **inp, return_all=True)
+    assert np.abs(out["logits"] - ref["logits"].numpy()).max() <= TOL["logit"]
+    assert np.abs(out["probs"] - ref["probs"].numpy()).max() <= TOL["prob"]
+    rp = ref["probs"].numpy()
+    srt = np.sort(rp, axis=-1)
+    clear = (srt[:, -1] - srt[:, -2]) > TOL["margin"]
+    assert (out["argmax"][clear] == ref["argmax"].numpy()[clear]).all()
+
+
+def test_f32_large_shape_is_refused_loudly(ctx):
+    from busca_amd import _lib
+    from busca_amd.dt import DecisionTransformerHIP
+    sd = synth.dt_state_dict(1, d=256, ff=512)
+    inp = synth.dt_inputs(1, 2, 11, 40)
+    m = DecisionTransformerHIP(ctx, sd, precision="f32")
+    with pytest.raises(_lib.BuscaError):
+        m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])
