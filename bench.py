@@ -187,6 +187,21 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev):
             "steps": n_steps}
 
 
+def assoc_e2e(frames):
+    """Simulated tracker frame (tools/e2e_sim.py): crops cut on the GPU, device-resident track memory, centre distances,
+    BUSCA.associate_embeddings on the SHIPPED model shape (d=512, L=11, P=5; config/*/*/*.yml) - the metric's
+    'p50 assoc latency'."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_sim
+    out = {}
+    for lost, objs in ((32, 150), (8, 60)):
+        r = e2e_sim.run(lost, objs, 5, 512, "f16", frames, verbose=False)
+        out["lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "p50_center_distance_ms",
+                                                                          "busca_frames_per_s", "device_resident_crops")}
+    out["config"] = "shipped model shape d=512 ff=1024 L=11 P=5, f16 MFMA DT + fp16 ReID, random weights, synthetic 1080p frames"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,7 +217,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--latency-samples", type=int, default=1000)
     ap.add_argument("--full-steps", type=int, default=6, help="full steps (ReID + DT) timed for `full_step` (0 = skip)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the secondary-precision / full-step measurements")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary-precision / full-step / end-to-end measurements")
+    ap.add_argument("--e2e-frames", type=int, default=20, help="frames of the simulated-tracker end-to-end leg (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -297,6 +313,11 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if rank == 0 and not args.no_variants and args.e2e_frames > 0:
+        try:
+            result["assoc_e2e"] = assoc_e2e(args.e2e_frames)
+        except Exception as e:      # the end-to-end leg is informative, never fatal for the contract line
+            result["assoc_e2e"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(result), flush=True)
 
