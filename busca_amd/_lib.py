@@ -35,6 +35,7 @@ SIGNATURES = {
     "busca_crop_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "busca_reid_blob_floats": (_sz, []),
     "busca_reid_load_weights": (C.c_int, [_vp, _vp, _sz]),
+    "busca_reid_load_weights_ex": (C.c_int, [_vp, _vp, _sz, _i32]),
     "busca_reid_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "busca_reid_workspace_bytes": (_sz, [_i32]),
 }

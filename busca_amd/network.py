@@ -69,6 +69,8 @@ class BUSCA:
                 raise NotImplementedError("only relu/gelu are built")
             self.effective_activation = args.activation
         self.precision = getattr(args, "precision", os.environ.get("BUSCA_AMD_PRECISION", "f32"))
+        # ReID flavour: "f16" (fp16 activations, fast) or "f32" (exact float32 convs, reference-exact, ~6x slower)
+        self.reid_precision = getattr(args, "reid_precision", os.environ.get("BUSCA_AMD_REID_PRECISION", "f16"))
         self.pinned_numpy = bool(getattr(args, "pinned_numpy_semantics", True))
         self.store_logits = False           # set True to fill .logits / .mem_logits like the reference does
         self.expected_image_size = _ReIDFacade.PRETRAINED_SIZE
@@ -164,7 +166,7 @@ class BUSCA:
             dt_sd = {k: v for k, v in self._sd.items() if not k.startswith(_REID_PREFIX)}
             self._dt = DecisionTransformerHIP(self._ctx, dt_sd, activation=self.effective_activation,
                                               fake_bbox_f64=self.pinned_numpy, precision=self.precision)
-            self._reid = ReIDEncoderHIP(self._ctx, self._sd, prefix=_REID_PREFIX)
+            self._reid = ReIDEncoderHIP(self._ctx, self._sd, prefix=_REID_PREFIX, precision=self.reid_precision)
             self._dirty = False
         return self._ctx
 

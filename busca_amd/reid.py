@@ -10,12 +10,14 @@ class ReIDEncoderHIP:
     `forward(crops_u8)`: u8 [n,384,128,3] BGR -> f32 [n,512] L2-normalised.  One call == one BN batch."""
     PRETRAINED_SIZE = (384, 128)
 
-    def __init__(self, ctx, state_dict, prefix=""):
+    def __init__(self, ctx, state_dict, prefix="", precision="f16"):
+        """precision "f16": fp16 activations/weights (fast); "f32": exact float32 convs (reference-exact, ~6x slower)."""
         self.ctx = ctx
+        self.precision = precision
         blob = weights.reid_blob(state_dict, prefix)
         want = ctx.lib.busca_reid_blob_floats()
         assert blob.size == want, (blob.size, want)
-        ctx.check(ctx.lib.busca_reid_load_weights(ctx.h, blob.ctypes.data, blob.size))
+        ctx.check(ctx.lib.busca_reid_load_weights_ex(ctx.h, blob.ctypes.data, blob.size, {"f16": 1, "f32": 0}[precision]))
 
     def forward(self, crops_u8, stream=None):
         dev = torch.device("cuda", self.ctx.device)

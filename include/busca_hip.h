@@ -133,7 +133,10 @@ int busca_crop_gather(busca_ctx* ctx, const uint8_t* frame, int32_t H, int32_t W
 /* ---- ReID feature extractor (busca/network.py:510-575 + busca/reid/resnet.py:266-322) --------- */
 /* Number of float32 values in the ReID weight blob (layout: see busca_amd/weights.py:reid_blob). */
 size_t busca_reid_blob_floats(void);
-int busca_reid_load_weights(busca_ctx* ctx, const float* blob, size_t blob_floats);
+int busca_reid_load_weights(busca_ctx* ctx, const float* blob, size_t blob_floats);      /* = _ex(..., BUSCA_PREC_F16) */
+/* precision BUSCA_PREC_F16: fp16 activations/weights, f32 accumulation and statistics (fast path).
+ * precision BUSCA_PREC_F32: float32 activations/weights on exact-f32 MFMA - reference-exact (~1e-5), ~6x slower. */
+int busca_reid_load_weights_ex(busca_ctx* ctx, const float* blob, size_t blob_floats, int32_t precision);
 /* crops: dev u8 [n,384,128,3] BGR (what the trackers keep in images_mem).  feats: dev f32 [n,512],
  * L2-normalised.  ONE CALL == ONE BatchNorm batch (train-mode statistics, network.py:553-556). */
 int busca_reid_forward(busca_ctx* ctx, const uint8_t* crops, int32_t n, float* feats, void* stream);

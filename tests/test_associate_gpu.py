@@ -122,3 +122,25 @@ def test_device_resident_track_memory(model):
                                        extra_kalman_candidates=[plain(t) for t in kal], normalize_ims=True)
     assert model.last_gather[0] == 0 and model.last_gather[1] > 0
     assert np.array_equal(a, b) and np.array_equal(ra, rb)
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_associate_exact_flavours_vs_reference(golden_dir, ci):
+    """f32 Decision Transformer + f32 ReID: the whole associate_embeddings output agrees with the reference's to
+    float32 round-off, and the one-hot decisions are identical."""
+    from busca_amd.network import BUSCA
+    a = _args(precision="f32")
+    a.reid_precision = "f32"
+    m = BUSCA(a).to(torch.device("cuda:0")).eval()
+    sd = dict(synth.dt_state_dict(17, d=64, ff=128))
+    sd.update({"reid_encoder.model." + k: v for k, v in synth.reid_state_dict(17).items()})
+    m.load_state_dict(sd)
+    g = np.load(os.path.join(golden_dir, "assoc.npz"))
+    name, tracks, dets, kals, P = _case(ci)
+    dists = g[name + "_dists"]
+    pm, rel = m.associate_embeddings(tracks, dets, dists, 11, P, True, False, extra_kalman_candidates=kals, normalize_ims=True)
+    ref = g["%s_probs_f64_sel0" % name]
+    assert np.array_equal(rel, g[name + "_reliable"])
+    assert np.abs(pm - ref).max() <= 2e-4, np.abs(pm - ref).max()
+    pm1, _ = m.associate_embeddings(tracks, dets, dists, 11, P, True, True, extra_kalman_candidates=kals, normalize_ims=True)
+    assert np.array_equal(pm1, g["%s_probs_f64_sel1" % name])

@@ -63,3 +63,38 @@ def test_reid_batch_composition_matters(model):
     assert np.array_equal(full, again)
     part = m.forward(crops[:3]).cpu().numpy()
     assert np.abs(part - full[:3]).max() > 1e-4
+
+
+def test_reid_f32_mode_matches_oracle(ctx):
+    """Exact-f32 flavour (f32 activations, v_mfma_f32_16x16x4_f32): float32-roundoff parity with the oracle, and it
+    bounds the fp16 flavour's deviation on the same batch."""
+    from busca_amd.reid import ReIDEncoderHIP
+    from oracle import reid as oreid
+    sd = synth.reid_state_dict(3)
+    crops = _crops(43, 3)
+    ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
+    m32 = ReIDEncoderHIP(ctx, sd, precision="f32")
+    got = m32.forward(crops).cpu().numpy()
+    assert np.abs(got - ref).max() <= 5e-5, np.abs(got - ref).max()
+    big = _crops(99, 24)
+    f32 = m32.forward(big).cpu().numpy()
+    m16 = ReIDEncoderHIP(ctx, sd, precision="f16")
+    f16 = m16.forward(big).cpu().numpy()
+    assert ((f32 * f16).sum(1) >= COS_MIN).all() and np.abs(f32 - f16).max() <= FEAT_ATOL
+
+
+def test_reid_golden_reference_features(ctx, golden_dir):
+    """Both flavours against features computed by the reference's own ReID_Encoder (tests/golden/reid.npz)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import smooth_crops
+    from busca_amd.reid import ReIDEncoderHIP
+    g = np.load(os.path.join(golden_dir, "reid.npz"))
+    sd = synth.reid_state_dict(3)
+    for n, seed in ((3, 43), (5, 45)):
+        ref = g["feats_n%d_seed%d" % (n, seed)]
+        crops = smooth_crops(seed, n)
+        got32 = ReIDEncoderHIP(ctx, sd, precision="f32").forward(crops).cpu().numpy()
+        assert np.abs(got32 - ref).max() <= 5e-5
+        got16 = ReIDEncoderHIP(ctx, sd, precision="f16").forward(crops).cpu().numpy()
+        assert ((got16 * ref).sum(1) >= COS_MIN).all()
