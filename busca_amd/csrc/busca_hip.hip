@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -51,7 +52,12 @@ struct busca_ctx {
     long long t_n = 0;
     int* crop_fill = nullptr;      // per-crop pad value scratch (busca_crop_gather)
     int crop_fill_cap = 0;
+    std::set<const void*> lds_configured;   // kernels whose dynamic-LDS limit was raised on THIS device
 };
+
+// Raise a kernel's dynamic LDS limit once per context (the attribute is per device, so a process driving several
+// GPUs through several contexts must set it for each).
+static int ensure_lds(busca_ctx* c, const void* kern, size_t bytes);
 
 static int fail(busca_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -67,6 +73,13 @@ static int fail(busca_ctx* c, int code, const char* fmt, ...) {
         hipError_t e__ = (call);                                                                           \
         if (e__ != hipSuccess) return fail((c), BUSCA_EHIP, "%s -> %s", #call, hipGetErrorString(e__));     \
     } while (0)
+
+static int ensure_lds(busca_ctx* c, const void* kern, size_t bytes) {
+    if (c->lds_configured.count(kern)) return BUSCA_OK;
+    HIP_TRY(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    c->lds_configured.insert(kern);
+    return BUSCA_OK;
+}
 
 extern "C" int busca_version(void) { return 1000; }
 
@@ -285,11 +298,7 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
     typedef DTLds<PREC, MT, D, FF, 512, NCH> LD;
     static_assert(LD::TOTAL <= 160 * 1024, "LDS plan exceeds 160 KiB");
     auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LD::TOTAL));
-        attr_set = true;
-    }
+    { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
     static const bool prof = getenv("BUSCA_DT_PROF") != nullptr;   // debug: phase timestamps of workgroup 0
     if (prof) {
         DTParams Q = P;
@@ -322,12 +331,11 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
 // ---- tiled (layer-wise) path ---------------------------------------------------------------------------------------
 template <int D, int EPI>
 static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblocks) {
-    const size_t lds = (size_t)(64 + D) * 128 + 2 * 4 * 64 * sizeof(float);
+    const size_t lds = (size_t)(DTL_BM + D) * 128 + 2 * 4 * DTL_BM * sizeof(float);
     auto kern = dtl_gemm_kernel<D, EPI>;
-    static bool attr = false;
-    if (!attr) { HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
     TimedLaunch tl(c, s);
-    hipLaunchKernelGGL(kern, dim3((a.M + 63) / 64, ncolblocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((a.M + DTL_BM - 1) / DTL_BM, ncolblocks), dim3(512), lds, s, a);
     return BUSCA_OK;
 }
 
@@ -336,8 +344,7 @@ static int dtl_attention(busca_ctx* c, hipStream_t s, const _Float16* qkv, _Floa
     constexpr int HD = D / 4, NCK = (MT + 1) / 2;
     const size_t lds = (size_t)16 * MT * (HD * 2 + 16) + (size_t)HD * (32 * NCK * 2 + 16);
     auto kern = dtl_attention_kernel<D, MT>;
-    static bool attr = false;
-    if (!attr) { HIP_TRY(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
     TimedLaunch tl(c, s);
     hipLaunchKernelGGL(kern, dim3(B, 4), dim3(256), lds, s, qkv, O, T, att);
     return BUSCA_OK;
