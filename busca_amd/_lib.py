@@ -32,6 +32,7 @@ SIGNATURES = {
     "busca_timing_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i32]),
     "busca_pairwise": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "busca_topk_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "busca_coverage": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "busca_crop_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "busca_reid_blob_floats": (_sz, []),
     "busca_reid_load_weights": (C.c_int, [_vp, _vp, _sz]),

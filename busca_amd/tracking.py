@@ -112,3 +112,59 @@ def get_bbox_crop(im, bbox_real_scale, output_size=(128, 384), normalize=True, g
         crop -= _PIXEL_MEAN
         crop /= (_PIXEL_STD if ghost_normalize else np.array([0.225, 0.224, 0.229]))
     return crop
+
+
+def get_detection_coverage(frame_shape, active_stracks, inactive_stracks=(), ctx=None):
+    """Share of the frame covered by the tracks' boxes and the per-object area statistics of the reliability gate
+    (adapters/ByteTrack/yolox/tracker/byte_tracker.py:574-623) - same dict as the reference; the pixel count comes
+    from busca_coverage instead of drawing filled rectangles on an H x W x 3 canvas.  `frame_shape` = frame.shape.
+    The reference's area normalisation divides the box WIDTH by the frame height and the box HEIGHT by the frame
+    width (:589); that is reproduced as is."""
+    H, W = int(frame_shape[0]), int(frame_shape[1])
+    rects, areas = [], []
+    for track in list(active_stracks) + list(inactive_stracks):
+        bb = np.array(track.tlbr) * track.scale
+        x1, y1, x2, y2 = int(bb[0]), int(bb[1]), int(bb[2]), int(bb[3])          # int() truncates toward zero
+        xa, xb, ya, yb = min(x1, x2), max(x1, x2), min(y1, y2), max(y1, y2)
+        if xb >= 0 and yb >= 0 and xa <= W - 1 and ya <= H - 1:                  # clipped rectangle is not empty
+            rects.append([max(xa, 0), max(ya, 0), min(xb, W - 1), min(yb, H - 1)])
+        areas.append(max(min(((bb[2] - bb[0]) / H) * ((bb[3] - bb[1]) / W), 1.0), 0.0))
+    n_obj = len(areas)
+    covered = 0
+    if rects:
+        ctx = ctx or geometry.default_context()
+        dev = torch.device("cuda", ctx.device)
+        r = torch.tensor(rects, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        ctx.check(ctx.lib.busca_coverage(ctx.h, r.data_ptr(), len(rects), H, W, cnt.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        covered = int(cnt.item())
+    pct = covered / (H * W)
+    if n_obj > 0:
+        avg_cov = pct / n_obj
+        avg_area = np.sqrt(np.array(areas)).mean() ** 2
+    else:
+        avg_cov, avg_area = 0.0, 0.0
+    return {"area_covered": pct, "area_covered_per_obj": avg_cov, "max_bbox_area": max(areas) if areas else 0.0,
+            "average_bbox_area": avg_area, "bbox_areas": areas}
+
+
+def is_reliable(frame_shape, active_stracks, p, ctx=None):
+    """byte_tracker.py:459-465: the frame is 'reliable' when the covered area exceeds p[0] * per-object area + p[1]."""
+    cov = get_detection_coverage(frame_shape, active_stracks, (), ctx=ctx)
+    return bool(cov["area_covered"] > cov["area_covered_per_obj"] * p[0] + p[1])
+
+
+def recover_with_busca(probs_matrix, reliable, n_dets, busca_thresh):
+    """Caller-side decision rule shared by the adapters (byte_tracker.py:504-527, StrongSORT tracker.py:347-371,
+    GHOST tracker.py:776-800): lost track i is recovered at its own Kalman prediction iff its memory is reliable
+    and probs[i, n_dets + i] > busca_thresh.  Returns (matches [[i, prob], ...], unmatched track indices)."""
+    matches, unmatched = [], []
+    if probs_matrix is None:
+        return matches, unmatched
+    for i in range(probs_matrix.shape[0]):
+        pr = probs_matrix[i, n_dets + i]
+        if reliable[i] and pr > busca_thresh:
+            matches.append([i, pr])
+        else:
+            unmatched.append(i)
+    return matches, unmatched

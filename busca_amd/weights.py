@@ -80,3 +80,24 @@ def reid_blob(state_dict, prefix=""):
                   _np(state_dict[prefix + bn + ".bias"]).ravel()]
     parts += [_np(state_dict[prefix + "red.weight"]).ravel(), _np(state_dict[prefix + "red.bias"]).ravel()]
     return np.concatenate(parts)
+
+
+def dt_unblob(blob, d, ff, nlayers, E=512):
+    """Inverse of dt_blob: flat float32 blob -> OrderedDict with the reference's key names and torch shapes."""
+    from collections import OrderedDict
+    shapes = {"encoder.weight": (d, E), "encoder.bias": (d,), "sep_token": (d,), "non_token": (d,), "bad_token": (d,),
+              "decoder.0.weight": (d,), "decoder.0.bias": (d,), "decoder.1.weight": (1, d), "decoder.1.bias": (1,)}
+    for i in range(nlayers):
+        p = "transformer_encoder.layers.%d." % i
+        shapes.update({p + "self_attn.in_proj_weight": (3 * d, d), p + "self_attn.in_proj_bias": (3 * d,),
+                       p + "self_attn.out_proj.weight": (d, d), p + "self_attn.out_proj.bias": (d,),
+                       p + "linear1.weight": (ff, d), p + "linear1.bias": (ff,), p + "linear2.weight": (d, ff), p + "linear2.bias": (d,),
+                       p + "norm1.weight": (d,), p + "norm1.bias": (d,), p + "norm2.weight": (d,), p + "norm2.bias": (d,)})
+    out, off = OrderedDict(), 0
+    blob = np.asarray(blob, dtype=np.float32)
+    for k in dt_blob_keys(nlayers):
+        n = int(np.prod(shapes[k]))
+        out[k] = blob[off:off + n].reshape(shapes[k]).copy()
+        off += n
+    assert off == blob.size
+    return out

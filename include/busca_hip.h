@@ -120,6 +120,12 @@ int busca_pairwise(busca_ctx* ctx, const double* a, int32_t nA, const double* b,
  * index; -1 pads rows when N < P (np.argsort(row)[:P] + None padding, network.py:333-338). */
 int busca_topk_rows(busca_ctx* ctx, const double* dist, int32_t B, int32_t N, int32_t P, int32_t* idx, void* stream);
 
+/* Detection coverage of the reliability gate (adapters/ByteTrack/yolox/tracker/byte_tracker.py:459-465,574-623):
+ * *count (dev u64) = pixels of an H x W frame covered by the union of n filled rectangles.  rects: dev i32 [n,4]
+ * x1,y1,x2,y2 with x1<=x2, y1<=y2, already int()-truncated and clipped to the frame (cv2.rectangle semantics, both
+ * corner pixels included). */
+int busca_coverage(busca_ctx* ctx, const int32_t* rects, int32_t n, int32_t H, int32_t W, uint64_t* count, void* stream);
+
 /* ---- crops (busca/tracking.py:62-113, busca/network.py:492-507) ------------------------------- */
 /*
  * frame: dev u8 [H,W,3] (BGR, row stride `stride` bytes); boxes: dev f32 [n,4] x1y1x2y2.

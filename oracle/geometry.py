@@ -207,3 +207,21 @@ def get_image_crops(im, bboxes, normalize=False):
     if not crops:
         return np.zeros([0, 128, 384, 3])
     return np.stack(crops, axis=0)
+
+
+def detection_coverage(frame_shape, boxes_tlbr_scaled):
+    """adapters/ByteTrack/yolox/tracker/byte_tracker.py:574-623 restated with a boolean canvas instead of cv2.rectangle
+    (third-party drawing, PARITY UNPINNED: filled rectangle = both int()-truncated corners inclusive, either corner
+    order, clipped to the canvas).  Returns the same dict as the reference."""
+    H, W = int(frame_shape[0]), int(frame_shape[1])
+    canvas = np.zeros((H, W), bool)
+    areas = []
+    for bb in boxes_tlbr_scaled:
+        x1, y1, x2, y2 = int(bb[0]), int(bb[1]), int(bb[2]), int(bb[3])
+        xa, xb, ya, yb = min(x1, x2), max(x1, x2), min(y1, y2), max(y1, y2)
+        canvas[max(ya, 0):max(yb + 1, 0), max(xa, 0):max(xb + 1, 0)] = True
+        areas.append(max(min(((bb[2] - bb[0]) / H) * ((bb[3] - bb[1]) / W), 1.0), 0.0))
+    pct = np.count_nonzero(canvas) / (H * W)
+    n = len(areas)
+    return {"area_covered": pct, "area_covered_per_obj": pct / n if n else 0.0, "max_bbox_area": max(areas) if areas else 0.0,
+            "average_bbox_area": (np.sqrt(np.array(areas)).mean() ** 2) if n else 0.0, "bbox_areas": areas}

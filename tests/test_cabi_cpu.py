@@ -69,3 +69,74 @@ def test_option_and_alias_package():
     import numpy as np
     assert center_distance([], []).shape == (0, 0)
     assert missing_candidate_bbox(flavour="ltwh").dtype == np.float64
+
+
+def _args(d=64):
+    import types, torch
+    return types.SimpleNamespace(num_layer=4, nhead=4, dim_embedding=512, trans_dim=d, ff_size=2 * d, activation="gelu", dropout_p=0.1,
+                                 input_flavour="MEM-SEP-CAN-BAD", output_flavour="CAN", encode_separator_as_reference=True,
+                                 encode_special_tokens=False, reid_weights_file="no", device=torch.device("cuda:0"))
+
+
+def test_load_pretrained_checkpoint_formats(tmp_path):
+    """BUSCA.load_pretrained (network.py:432-467): raw state_dict or {'model_state_dict', 'optimizer_state_dict'};
+    ReID classifier / whole-ReID dropping; foreign keys (cls_token, BN buffers, fc) are ignored.  No GPU needed."""
+    import numpy as np, torch
+    from busca_amd import synth
+    from busca_amd.network import BUSCA
+    m = BUSCA(_args())
+    sd = {k: torch.from_numpy(v) for k, v in synth.dt_state_dict(99, d=64, ff=128).items()}
+    sd.update({"reid_encoder.model." + k: torch.from_numpy(v) for k, v in synth.reid_state_dict(99, with_fc=True).items()})
+    sd["cls_token"] = torch.zeros(64)
+    sd["reid_encoder.model.bn1.running_mean"] = torch.zeros(64)
+    sd["reid_encoder.model.bn1.num_batches_tracked"] = torch.tensor(5)
+    before_reid = m._sd["reid_encoder.model.conv1.weight"].copy()
+    p1 = tmp_path / "raw.pth"
+    torch.save(sd, p1)
+    m.load_pretrained(str(p1), ignore_reid_fc=True)
+    assert np.array_equal(m._sd["encoder.weight"], sd["encoder.weight"].numpy()) and m._dirty
+    assert np.array_equal(m._sd["reid_encoder.model.conv1.weight"], sd["reid_encoder.model.conv1.weight"].numpy())
+    assert "reid_encoder.model.fc.weight" not in m._sd and "cls_token" not in m._sd
+    m2 = BUSCA(_args())
+    p2 = tmp_path / "wrapped.pth"
+    torch.save({"model_state_dict": sd, "optimizer_state_dict": {}}, p2)
+    m2.load_pretrained(str(p2), ignore_reid=True)
+    assert np.array_equal(m2._sd["sep_token"], sd["sep_token"].numpy())
+    assert np.array_equal(m2._sd["reid_encoder.model.conv1.weight"], before_reid) or not np.array_equal(
+        m2._sd["reid_encoder.model.conv1.weight"], sd["reid_encoder.model.conv1.weight"].numpy())
+    # state_dict round trip and size check
+    out = m.state_dict()
+    assert set(out) == set(m._sd) and out["encoder.weight"].shape == (64, 512)
+    import pytest
+    bad = dict(sd)
+    bad["encoder.weight"] = torch.zeros(3, 3)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+
+
+def test_unsupported_configs_raise_like_the_reference():
+    import pytest
+    from busca_amd.network import BUSCA
+    a = _args(); a.input_flavour = "CLS-MEM-SEP-CAN"
+    with pytest.raises(NotImplementedError):
+        BUSCA(a)
+    a = _args(); a.activation = "swish"
+    with pytest.raises(RuntimeError):
+        BUSCA(a)
+    import torch
+    a = _args(); a.device = torch.device("cpu")
+    with pytest.raises(RuntimeError):
+        BUSCA(a)
+
+
+def test_blob_round_trip_and_decision_rule():
+    import numpy as np
+    from busca_amd import synth, weights
+    from busca_amd.tracking import recover_with_busca
+    sd = synth.dt_state_dict(5, d=64, ff=128)
+    back = weights.dt_unblob(weights.dt_blob(sd, 4), 64, 128, 4)
+    assert list(back) == weights.dt_blob_keys(4) and all(np.array_equal(back[k], sd[k]) for k in back)
+    probs = np.zeros((3, 5 + 3)); probs[0, 5] = 0.9; probs[1, 6] = 0.4; probs[2, 7] = 0.95
+    matches, unmatched = recover_with_busca(probs, np.array([True, True, False]), 5, 0.5)
+    assert matches == [[0, 0.9]] and unmatched == [1, 2]
+    assert recover_with_busca(None, None, 5, 0.5) == ([], [])

@@ -115,3 +115,26 @@ def test_crop_gather_empty(ctx):
     from busca_amd import geometry as G
     u8, _ = G.crop_gather(ctx, _frame(1, 64, 64), np.zeros((0, 4), np.float32))
     assert tuple(u8.shape) == (0, 384, 128, 3)
+
+
+def test_detection_coverage_bit_exact(ctx):
+    """Reliability-gate coverage (union area of filled rectangles) vs the oracle's boolean-canvas restatement."""
+    import types
+    from busca_amd import tracking
+    from oracle import geometry as og
+    H, W = 1080, 1920
+    b = _boxes(77, 300)
+    b[0] = [-50.7, -20.2, 30.9, 80.1]          # clipped at the top-left, negative coordinates truncate toward zero
+    b[1] = [1900.0, 1000.0, 2500.0, 1500.0]    # clipped bottom-right
+    b[2] = [3000.0, 100.0, 3100.0, 200.0]      # outside
+    b[3] = [400.9, 300.9, 400.1, 300.1]        # degenerate: a single pixel after truncation
+    b[4] = [500.0, 600.0, 450.0, 550.0]        # corners swapped
+    tracks = [types.SimpleNamespace(tlbr=bb / 1.25, scale=1.25) for bb in b]
+    got = tracking.get_detection_coverage((H, W, 3), tracks[:200], tracks[200:], ctx=ctx)
+    ref = og.detection_coverage((H, W, 3), [np.array(t.tlbr) * t.scale for t in tracks])
+    assert got["area_covered"] == ref["area_covered"] and got["area_covered_per_obj"] == ref["area_covered_per_obj"]
+    assert got["max_bbox_area"] == ref["max_bbox_area"] and got["average_bbox_area"] == ref["average_bbox_area"]
+    assert got["bbox_areas"] == ref["bbox_areas"]
+    empty = tracking.get_detection_coverage((H, W, 3), [], [], ctx=ctx)
+    assert empty["area_covered"] == 0.0 and empty["bbox_areas"] == []
+    assert tracking.is_reliable((H, W, 3), tracks[:50], (3.0, 0.0), ctx=ctx) in (True, False)
