@@ -39,6 +39,7 @@ SIGNATURES = {
     "busca_reid_load_weights_ex": (C.c_int, [_vp, _vp, _sz, _i32]),
     "busca_reid_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "busca_reid_workspace_bytes": (_sz, [_i32]),
+    "busca_bn_stats_1x1": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -19,6 +19,7 @@
 #include "pairwise_kernel.hip.inc"
 #include "crop_kernel.hip.inc"
 #include "reid_kernel.hip.inc"
+#include "reid_gram.hip.inc"
 #include "reid_f32.hip.inc"
 #include "dt_tiled.hip.inc"
 

@@ -148,6 +148,18 @@ int busca_reid_load_weights_ex(busca_ctx* ctx, const float* blob, size_t blob_fl
 int busca_reid_forward(busca_ctx* ctx, const uint8_t* crops, int32_t n, float* feats, void* stream);
 /* Bytes of device workspace busca_reid_forward needs for n crops (allocated lazily inside the ctx). */
 size_t busca_reid_workspace_bytes(int32_t n);
+/*
+ * Building block of the large-batch ReID schedule, exposed for unit tests: train-mode BatchNorm (scale, shift) of a
+ * 1x1 conv y = w x of stride `stride` WITHOUT running the conv, from the Gram matrix of its input
+ * (nn.BatchNorm2d batch statistics, network.py:553-556, of resnet.py:108-128's conv3 / downsample).
+ *   x      dev fp16 NHWC [n,H,W,Cin] (Cin 64 or a multiple of 128, <= 512);  in_ss dev f32 [Cin][2] or NULL: when given,
+ *          the conv's input is relu(x*scale+shift) rounded to fp16 (the producer's BatchNorm, applied on the fly)
+ *   w      dev fp16 [Cout][Cin];  gamma, beta dev f32 [Cout];  ss_out dev f32 [Cout][2] = (scale, shift), eps 1e-5
+ * Synchronises `stream` (scratch is allocated and freed inside the call).
+ */
+int busca_bn_stats_1x1(busca_ctx* ctx, const void* x, const float* in_ss, int32_t n, int32_t H, int32_t W, int32_t Cin,
+                       int32_t stride, const void* w, int32_t Cout, const float* gamma, const float* beta, float* ss_out,
+                       void* stream);
 
 #ifdef __cplusplus
 }

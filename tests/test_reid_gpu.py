@@ -98,3 +98,30 @@ def test_reid_golden_reference_features(ctx, golden_dir):
         assert np.abs(got32 - ref).max() <= 5e-5
         got16 = ReIDEncoderHIP(ctx, sd, precision="f16").forward(crops).cpu().numpy()
         assert ((got16 * ref).sum(1) >= COS_MIN).all()
+
+
+@pytest.mark.parametrize("n", [5, 24])
+def test_reid_gram_statistics_path(ctx, monkeypatch, n):
+    """Large batches take BN3 / downsample-BN statistics from the Gram matrix of the conv's input and fuse the downsample
+    conv into the block tail (reid_gram.hip.inc).  Forced on at a small batch it must reproduce the direct-statistics
+    schedule (same roundings of every stored tensor; statistics differ at the 1e-7 level) and stay on the oracle."""
+    from busca_amd.reid import ReIDEncoderHIP
+    from oracle import reid as oreid
+    sd = synth.reid_state_dict(3)
+    crops = _crops(300 + n, n)
+    monkeypatch.setenv("BUSCA_REID_GRAM", "0")
+    direct = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
+    monkeypatch.setenv("BUSCA_REID_GRAM", "1")
+    m = ReIDEncoderHIP(ctx, sd)
+    gram = m.forward(crops).cpu().numpy()
+    assert np.array_equal(gram, m.forward(crops).cpu().numpy())            # deterministic
+    # the two schedules differ only in how the statistics are summed (~1e-7), but one flipped fp16 rounding early in the
+    # network moves the features by ~2e-3; both sit at the same distance (~6e-3) from the exact-f32 flavour
+    assert np.abs(gram - direct).max() <= 5e-3, np.abs(gram - direct).max()
+    assert ((gram * direct).sum(1)).min() >= 0.9998
+    if n <= 8:
+        ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
+        assert (gram * ref).sum(1).min() >= COS_MIN
+        assert np.abs(gram - ref).max() <= FEAT_ATOL
+    monkeypatch.delenv("BUSCA_REID_GRAM")
+    ReIDEncoderHIP(ctx, sd)                                                   # leave the shared ctx in auto mode
