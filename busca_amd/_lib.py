@@ -56,7 +56,7 @@ def load():
         # copy is already loaded, this library's NEEDED libamdhip64.so.7 binds to it and both share ONE HIP
         # runtime (same device pointers, same streams).  Loading in the other order gives two runtimes.
         import torch  # noqa: F401
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(os.environ.get("BUSCA_HIP_LIB", LIB_PATH))      # override: experiment builds of the same ABI
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res
