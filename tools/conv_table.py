@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Per-shape conv throughput from a rocprofv3 rocpd db of tools/reid_bench.py: conv_table.py db n_crops"""
+"""Per-shape conv throughput from a rocprofv3 rocpd db of tools/reid_bench.py: conv_table.py db n_crops [--direct]
+(--direct: the trace was taken with BUSCA_REID_GRAM=0; default assumes the automatic schedule)"""
 import sqlite3, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from busca_amd import synth
 db, n = sys.argv[1], int(sys.argv[2])
+direct = '--direct' in sys.argv
 con = sqlite3.connect(db)
 rows = con.execute("select name, start, end from kernels where name like '%conv_gemm%' order by start").fetchall()
 specs = synth.reid_conv_specs()
@@ -19,10 +21,15 @@ for li, nb in enumerate((3, 4, 6, 3)):
         n2 = specs[i + 1]; o2 = osz(*o1, n2[3], n2[4], n2[5]); out.append((n2[2], n2[1], n2[3], *o2, "conv2"))
         n3 = specs[i + 2]; o3 = osz(*o2, n3[3], n3[4], n3[5])
         i += 3
+        gram = (not direct) and li <= 2 and n * o3[0] * o3[1] >= 65536      # capi_reid.hip.inc: reid_use_gram
         if b == 0:
-            nd = specs[i]; od = osz(h, w, nd[3], nd[4], nd[5]); out.append((nd[2], nd[1], nd[3], *od, "down")); i += 1
-        out.append((n3[2], n3[1], n3[3], *o3, "conv3-stats"))
-        out.append((n3[2], n3[1], n3[3], *o3, "conv3-merge"))
+            nd = specs[i]; od = osz(h, w, nd[3], nd[4], nd[5]); i += 1
+            if not gram: out.append((nd[2], nd[1], nd[3], *od, "down"))
+        if gram:
+            out.append((n3[2] + (nd[2] if b == 0 else 0), n3[1], n3[3], *o3, "tail+down" if b == 0 else "tail"))
+        else:
+            out.append((n3[2], n3[1], n3[3], *o3, "conv3-stats"))
+            out.append((n3[2], n3[1], n3[3], *o3, "tail"))
         h, w = o3
 last = rows[-len(out):]
 agg = {}
