@@ -17,6 +17,7 @@
 
 #include "dt_kernel.hip.inc"
 #include "pairwise_kernel.hip.inc"
+#include "track_kernel.hip.inc"
 #include "crop_kernel.hip.inc"
 #include "reid_kernel.hip.inc"
 #include "reid_gram.hip.inc"

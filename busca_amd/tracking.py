@@ -52,6 +52,44 @@ def iou_distance(atlbrs, btlbrs, det_scores=None, ctx=None):
     ctx = ctx or geometry.default_context()
     return geometry.pairwise(ctx, a, b, _lib.PAIR_IOU_COST, scores_b=det_scores).cpu().numpy()
 
+TRACKED = 1     # TrackState.Tracked (adapters/*/mot_online/basetrack.py:5-9)
+
+
+def multi_predict(stracks, ctx=None):
+    """STrack.multi_predict (adapters/ByteTrack/yolox/tracker/byte_tracker.py:50-61) on the GPU: constant-velocity Kalman
+    prediction of every track's (mean [8], covariance [8,8]) in place; `mean[7]` of non-Tracked tracks is zeroed first."""
+    if len(stracks) == 0:
+        return
+    ctx = ctx or geometry.default_context()
+    dev = torch.device("cuda", ctx.device)
+    mean = torch.from_numpy(np.asarray([st.mean for st in stracks], dtype=np.float64)).to(dev)
+    cov = torch.from_numpy(np.asarray([st.covariance for st in stracks], dtype=np.float64)).to(dev)
+    nt = torch.from_numpy(np.asarray([st.state != TRACKED for st in stracks], dtype=np.uint8)).to(dev)
+    ctx.check(ctx.lib.busca_kalman_multi_predict(ctx.h, mean.data_ptr(), cov.data_ptr(), nt.data_ptr(), len(stracks),
+                                                 torch.cuda.current_stream(dev).cuda_stream))
+    mean, cov = mean.cpu().numpy(), cov.cpu().numpy()
+    for i, st in enumerate(stracks):
+        st.mean = mean[i]
+        st.covariance = cov[i]
+
+
+def remove_duplicate_stracks(stracksa, stracksb, ctx=None, thresh=0.15):
+    """remove_duplicate_stracks (byte_tracker.py:685-698): of two tracks whose IoU cost is below 0.15 the one alive for
+    fewer frames goes (ties: the one of the first list).  IoU cost and the marking both run on the GPU."""
+    if len(stracksa) == 0 or len(stracksb) == 0:
+        return list(stracksa), list(stracksb)
+    ctx = ctx or geometry.default_context()
+    dev = torch.device("cuda", ctx.device)
+    cost = geometry.pairwise(ctx, _tlbrs(stracksa), _tlbrs(stracksb), _lib.PAIR_IOU_COST)
+    age_a = torch.tensor([t.frame_id - t.start_frame for t in stracksa], dtype=torch.int32, device=dev)
+    age_b = torch.tensor([t.frame_id - t.start_frame for t in stracksb], dtype=torch.int32, device=dev)
+    keep_a = torch.empty(len(stracksa), dtype=torch.uint8, device=dev)
+    keep_b = torch.empty(len(stracksb), dtype=torch.uint8, device=dev)
+    ctx.check(ctx.lib.busca_duplicate_masks(ctx.h, cost.data_ptr(), len(stracksa), len(stracksb), age_a.data_ptr(), age_b.data_ptr(),
+                                            float(thresh), keep_a.data_ptr(), keep_b.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    ka, kb = keep_a.cpu().numpy(), keep_b.cpu().numpy()
+    return [t for i, t in enumerate(stracksa) if ka[i]], [t for i, t in enumerate(stracksb) if kb[i]]
+
 
 _PIXEL_MEAN = np.array([0.406, 0.456, 0.485])   # BGR
 _PIXEL_STD = np.array([0.225, 0.224, 0.299])    # BGR; 0.299 is the reference's "ghost" normalisation

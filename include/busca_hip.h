@@ -126,6 +126,20 @@ int busca_topk_rows(busca_ctx* ctx, const double* dist, int32_t B, int32_t N, in
  * corner pixels included). */
 int busca_coverage(busca_ctx* ctx, const int32_t* rects, int32_t n, int32_t H, int32_t W, uint64_t* count, void* stream);
 
+/* ---- track state of the association rounds ------------------------------------------------ */
+/* STrack.multi_predict (adapters/ByteTrack/yolox/tracker/byte_tracker.py:50-61): constant-velocity Kalman prediction
+ * of n tracks in place.  mean dev f64 [n,8] (x,y,a,h,vx,vy,va,vh), cov dev f64 [n,8,8]; not_tracked dev u8 [n] or NULL:
+ * 1 zeroes mean[7] first (state != Tracked, :55-56).  Process noise: std weights 1/20 (position) and 1/160 (velocity)
+ * times the box height, 1e-2 / 1e-5 for the aspect ratio (KalmanFilter.multi_predict,
+ * adapters/CenterTrack/src/lib/utils/mot_online/kalman_filter.py:154-190 - the copy byte_tracker.py:15 falls back to).
+ * Bit-exact against the numpy evaluation. */
+int busca_kalman_multi_predict(busca_ctx* ctx, double* mean, double* cov, const uint8_t* not_tracked, int32_t n, void* stream);
+/* remove_duplicate_stracks (byte_tracker.py:685-698) on an IoU-cost matrix cost[nA,nB] (dev f64, busca_pairwise
+ * IOU_COST): for every pair with cost < thresh (0.15) the track with the smaller age (frame_id - start_frame, dev i32)
+ * is dropped; ties drop the A track.  keep_a [nA], keep_b [nB] dev u8: 1 = keep. */
+int busca_duplicate_masks(busca_ctx* ctx, const double* cost, int32_t nA, int32_t nB, const int32_t* age_a, const int32_t* age_b,
+                          double thresh, uint8_t* keep_a, uint8_t* keep_b, void* stream);
+
 /* ---- crops (busca/tracking.py:62-113, busca/network.py:492-507) ------------------------------- */
 /*
  * frame: dev u8 [H,W,3] (BGR, row stride `stride` bytes); boxes: dev f32 [n,4] x1y1x2y2.

@@ -308,12 +308,41 @@ def make_assoc(ref):
     print("wrote assoc")
 
 
+def make_track(ref):
+    """Kalman prediction of STrack.multi_predict (byte_tracker.py:50-61) through the reference's vendored KalmanFilter
+    (adapters/CenterTrack/src/lib/utils/mot_online/kalman_filter.py, the adapter's fallback import)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_kalman_filter", os.path.join(REF, "adapters/CenterTrack/src/lib/utils/mot_online/kalman_filter.py"))
+    kfm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kfm)
+    kf = kfm.KalmanFilter()
+    n = 37
+    cx, cy = synth.uniform(11, "cx", (n,), 50, 1800), synth.uniform(11, "cy", (n,), 50, 1000)
+    hh = synth.uniform(11, "h", (n,), 30, 500)
+    ar = synth.uniform(11, "a", (n,), 0.25, 0.6)
+    means, covs = [], []
+    for i in range(n):
+        m, c = kf.initiate(np.array([cx[i], cy[i], ar[i], hh[i]], dtype=np.float64))
+        for step in range(1 + i % 3):                    # a few predict/update cycles: dense covariance, non-zero velocities
+            m, c = kf.predict(m, c)
+            z = np.array([cx[i] + 3.0 * (step + 1), cy[i] - 2.0 * (step + 1), ar[i] * 1.01, hh[i] * 1.02])
+            m, c = kf.update(m, c, z)
+        means.append(m); covs.append(c)
+    mean, cov = np.asarray(means), np.asarray(covs)
+    not_tracked = (synth.uniform(11, "st", (n,), 0, 1) < 0.4)
+    mm = mean.copy()                                     # byte_tracker.py:52-57
+    mm[not_tracked, 7] = 0
+    pm, pc = kf.multi_predict(mm, cov)
+    np.savez_compressed(os.path.join(OUT, "track.npz"), mean=mean, cov=cov, not_tracked=not_tracked, pred_mean=pm, pred_cov=pc)
+    print("wrote track", pm.shape, pc.shape)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"dt", "enc", "geom", "assoc", "reid"}
+    which = set(sys.argv[1:]) or {"dt", "enc", "geom", "assoc", "reid", "track"}
     ref = import_reference()
     if "dt" in which:
         make_dt(ref)
-    for name in ("enc", "geom", "assoc", "reid"):
+    for name in ("enc", "geom", "assoc", "reid", "track"):
         fn = globals().get("make_" + name)
         if name in which and fn is not None:
             fn(ref)
