@@ -21,6 +21,7 @@
 #include "crop_kernel.hip.inc"
 #include "reid_kernel.hip.inc"
 #include "reid_gram.hip.inc"
+#include "reid_halo.hip.inc"
 #include "reid_f32.hip.inc"
 #include "dt_tiled.hip.inc"
 
