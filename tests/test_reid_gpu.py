@@ -125,3 +125,23 @@ def test_reid_gram_statistics_path(ctx, monkeypatch, n):
         assert np.abs(gram - ref).max() <= FEAT_ATOL
     monkeypatch.delenv("BUSCA_REID_GRAM")
     ReIDEncoderHIP(ctx, sd)                                                   # leave the shared ctx in auto mode
+
+
+def test_reid_halo_conv_path(ctx, monkeypatch):
+    """Large batches run the stride-1 3x3 convs of layers 1-3 through the halo-resident kernel (reid_halo.hip.inc; all
+    three variants are active from 96 crops).  Same stored roundings as the generic kernel; only the f32 summation order
+    inside a conv differs."""
+    from busca_amd.reid import ReIDEncoderHIP
+    sd = synth.reid_state_dict(3)
+    n = 198
+    crops = _crops(900, n)
+    monkeypatch.setenv("BUSCA_REID_HALO", "0")
+    generic = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
+    monkeypatch.setenv("BUSCA_REID_HALO", "1")
+    m = ReIDEncoderHIP(ctx, sd)
+    halo = m.forward(crops).cpu().numpy()
+    assert np.array_equal(halo, m.forward(crops).cpu().numpy())
+    assert np.abs(halo - generic).max() <= 5e-3, np.abs(halo - generic).max()
+    assert (halo * generic).sum(1).min() >= 0.9998
+    monkeypatch.delenv("BUSCA_REID_HALO")
+    ReIDEncoderHIP(ctx, sd)
