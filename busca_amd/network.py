@@ -195,6 +195,10 @@ class BUSCA:
         """The two BatchNorm batches of a step (memory crops, candidate crops; network.py:192-193) are independent:
         the candidate batch runs on a side stream, concurrently with the memory batch (per-stream workspaces in the
         library).  Small batches are latency-bound, so this nearly halves their ReID time."""
+        return self._reid_join(self._reid_side_start(can_u8), self._reid.forward(mem_u8))
+
+    def _reid_side_start(self, u8):
+        """Enqueue one BatchNorm batch on the side stream (ordered after everything already on the current stream)."""
         dev = self._dev()
         cur = torch.cuda.current_stream(dev)
         if getattr(self, "_side_stream", None) is None:
@@ -202,12 +206,16 @@ class BUSCA:
         side = self._side_stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            can_feat = self._reid.forward(can_u8, stream=side.cuda_stream)
-        can_u8.record_stream(side)
-        mem_feat = self._reid.forward(mem_u8)
-        cur.wait_stream(side)
-        can_feat.record_stream(cur)
-        return mem_feat, can_feat
+            feat = self._reid.forward(u8, stream=side.cuda_stream)
+        u8.record_stream(side)
+        return feat
+
+    def _reid_join(self, side_feat, cur_feat):
+        """Make the current stream wait for the side-stream batch; returns (cur_feat, side_feat)."""
+        cur = torch.cuda.current_stream(self._dev())
+        cur.wait_stream(self._side_stream)
+        side_feat.record_stream(cur)
+        return cur_feat, side_feat
 
     # ---- forward ------------------------------------------------------------------------------------------------
     def forward(self, embeddings_memory, candidate_embedding, memory_bboxes=None, candidates_bboxes=None,
@@ -268,12 +276,15 @@ class BUSCA:
             hist = trk.images_mem
             idx = memory_indices(len(hist), L, use_broader_memory)
             if len(idx) == L:
-                for j, i in enumerate(idx):
-                    mem_ref[t][j] = hist[i]
-                    mem_box[t, j] = np.asarray(trk.tlwh_mem[i], dtype=np.float64) * trk.scale
+                mem_ref[t] = [hist[i] for i in idx]
+                mem_box[t] = np.asarray([trk.tlwh_mem[i] for i in idx], dtype=np.float64) * trk.scale
                 reliable[t] = True
             else:                               # incomplete memory: zero crops, dummy box, flagged unreliable
                 mem_box[t] = (250.0, 250.0, 500.0, 500.0)
+
+        # the memory batch does not depend on the proposals: its ReID pass is enqueued NOW (side stream), so the host work
+        # below (top-P selection, candidate lists) is hidden behind it
+        mem_feat_side = self._reid_side_start(self._gather_crops(mem_ref, as_u8))
 
         # top-P nearest detections per track on the GPU (ascending centre distance, ties by lower index)
         order = np.full((B, P), -1, np.int64)
@@ -310,7 +321,7 @@ class BUSCA:
             mem_ltrb[..., 2:] += mem_ltrb[..., :2]
             can_ltrb[..., 2:] += can_ltrb[..., :2]
 
-        mem_feat, can_feat = self._reid_pair(self._gather_crops(mem_ref, as_u8), self._gather_crops(can_ref, as_u8))
+        can_feat, mem_feat = self._reid_join(mem_feat_side, self._reid.forward(self._gather_crops(can_ref, as_u8)))
         mem_feat, can_feat = mem_feat.view(B, L, -1), can_feat.view(B, P, -1)     # two BN batches
         out = self._dt.forward(mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=self.store_logits)
         self._last = out
