@@ -198,6 +198,8 @@ def assoc_e2e(frames):
         r = e2e_sim.run(lost, objs, 5, 512, "f16", frames, verbose=False)
         out["lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "p50_center_distance_ms",
                                                                           "busca_frames_per_s", "device_resident_crops")}
+    r = e2e_sim.run(8, 60, 5, 512, "f16", frames, verbose=False, device_only_crops=True)     # opt-in: crops never copied back to the host
+    out["lost8_dets52_device_only_crops"] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "busca_frames_per_s")}
     out["config"] = "shipped model shape d=512 ff=1024 L=11 P=5, f16 MFMA DT + fp16 ReID, random weights, synthetic 1080p frames"
     return out
 

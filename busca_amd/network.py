@@ -72,6 +72,8 @@ class BUSCA:
         # ReID flavour: "f16" (fp16 activations, fast) or "f32" (exact float32 convs, reference-exact, ~6x slower)
         self.reid_precision = getattr(args, "reid_precision", os.environ.get("BUSCA_AMD_REID_PRECISION", "f16"))
         self.pinned_numpy = bool(getattr(args, "pinned_numpy_semantics", True))
+        # True: get_image_crops(normalize=False) keeps the crops on the GPU only (host arrays are placeholders)
+        self.device_only_crops = bool(getattr(args, "device_only_crops", False))
         self.store_logits = False           # set True to fill .logits / .mem_logits like the reference does
         self.expected_image_size = _ReIDFacade.PRETRAINED_SIZE
         self.reid_encoder = _ReIDFacade(self)
@@ -261,6 +263,8 @@ class BUSCA:
         H, W = self.expected_image_size
 
         def as_u8(img):
+            if not getattr(img, "host_valid", True):
+                raise RuntimeError("a device-only crop (device_only_crops=True) lost its GPU twin: its host bytes were never copied")
             img = np.asarray(img)
             if img.dtype == np.uint8:
                 return img
@@ -384,7 +388,7 @@ class BUSCA:
         if output_size is not None and tuple(output_size) != (self.expected_image_size[1], self.expected_image_size[0]):
             raise NotImplementedError("only the ReID crop size 128x384 is built")
         self._sync()
-        return tracking.get_image_crops(image, bboxes, normalize=normalize, ctx=self._ctx)
+        return tracking.get_image_crops(image, bboxes, normalize=normalize, ctx=self._ctx, device_only=self.device_only_crops)
 
 
 class ReID_Encoder(_ReIDFacade):

@@ -110,15 +110,20 @@ class DeviceBackedCrops(np.ndarray):
     uint8 array ([N,384,128,3]; `crops[i]` is what they append to `images_mem`), but every view also carries
     `.dev`, the matching slice of the CUDA tensor the crop kernel wrote.  `associate_embeddings` gathers the
     `.dev` views on the GPU and skips the per-frame host->device copy of B*(L+P) crops (147 KB each); crops
-    that lost their twin (np.array(...) copies, other sources) silently take the host path."""
+    that lost their twin (np.array(...) copies, other sources) silently take the host path.
 
-    def __new__(cls, host, dev):
+    `host_valid` is False for the placeholders of `get_image_crops(..., device_only=True)`: their host bytes were never
+    copied back (a zero-stride all-zero array), only `.dev` carries pixels."""
+
+    def __new__(cls, host, dev, host_valid=True):
         obj = np.asarray(host).view(cls)
         obj.dev = dev
+        obj.host_valid = host_valid
         return obj
 
     def __array_finalize__(self, obj):
         self.dev = None                     # generic views/copies do not know which device rows they cover
+        self.host_valid = getattr(obj, "host_valid", True)
 
     def __getitem__(self, key):
         out = super().__getitem__(key)
@@ -127,13 +132,18 @@ class DeviceBackedCrops(np.ndarray):
         return out
 
 
-def get_image_crops(im, bboxes, normalize=True, ctx=None):
-    """All crops of one frame in one launch: u8 BGR [N,384,128,3] (float32 normalised if `normalize`)."""
+def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False):
+    """All crops of one frame in one launch: u8 BGR [N,384,128,3] (float32 normalised if `normalize`).
+    `device_only` (with normalize=False): skip the device->host copy of the crops (147 KB each, the bulk of this call);
+    the returned array is a zero-stride placeholder whose `crops[i]` still carry `.dev` - for trackers that only hand the
+    crops back to `associate_embeddings`, which is all the reference's adapters do with them."""
     bboxes = np.asarray(bboxes, dtype=np.float32).reshape(-1, 4)
     if len(bboxes) == 0:
         return np.zeros([0, 128, 384, 3])            # the reference's (transposed) empty shape, network.py:503
     ctx = ctx or geometry.default_context()
     u8, _ = geometry.crop_gather(ctx, im, bboxes, want_u8=True)
+    if device_only and not normalize:
+        return DeviceBackedCrops(np.broadcast_to(np.zeros(1, np.uint8), tuple(u8.shape)), u8, host_valid=False)
     crops = u8.cpu().numpy()
     if normalize:
         return normalize_crops(crops)

@@ -144,3 +144,35 @@ def test_associate_exact_flavours_vs_reference(golden_dir, ci):
     assert np.abs(pm - ref).max() <= 2e-4, np.abs(pm - ref).max()
     pm1, _ = m.associate_embeddings(tracks, dets, dists, 11, P, True, True, extra_kalman_candidates=kals, normalize_ims=True)
     assert np.array_equal(pm1, g["%s_probs_f64_sel1" % name])
+
+
+def test_device_only_crops(model):
+    """device_only_crops: get_image_crops skips the device->host copy; the placeholders still associate through their GPU
+    twins (bit-identical), and a placeholder that lost its twin is refused instead of silently contributing zeros."""
+    import make_golden as mg
+    model.pinned_numpy = True
+    model._dirty = True
+    frame = synth.randint_u8(4, "frame", (540, 960, 3))
+    boxes = np.array([[50 + 30 * i, 40 + 5 * i, 110 + 30 * i, 260 + 5 * i] for i in range(24)], np.float32)
+
+    def scene(crops):
+        hist = [mg.FakeTrack([[50, 40, 60, 220]] * 12, [crops[i] for i in range(12)]), mg.FakeTrack([[300, 80, 60, 220]] * 11, [crops[i] for i in range(12, 23)])]
+        dets = [mg.FakeTrack([[55, 45, 60, 220]], [crops[23]]), mg.FakeTrack([[310, 85, 60, 220]], [crops[5]])]
+        kal = [mg.FakeTrack([[52, 42, 60, 220]], [crops[1]]), mg.FakeTrack([[305, 82, 60, 220]], [crops[14]])]
+        return hist, dets, kal
+    dists = np.array([[7.0, 250.0], [250.0, 11.0]])
+    h, d, k = scene(model.get_image_crops(frame, boxes, normalize=False))
+    a, ra = model.associate_embeddings(h, d, dists, 11, 5, True, False, extra_kalman_candidates=k, normalize_ims=True)
+    model.device_only_crops = True
+    try:
+        crops = model.get_image_crops(frame, boxes, normalize=False)
+        assert crops.shape == (24, 384, 128, 3) and crops.strides == (0, 0, 0, 0) and not crops[2].host_valid and crops[2].dev is not None
+        h, d, k = scene(crops)
+        b, rb = model.associate_embeddings(h, d, dists, 11, 5, True, False, extra_kalman_candidates=k, normalize_ims=True)
+        assert model.last_gather[1] == 0
+        assert np.array_equal(a, b) and np.array_equal(ra, rb)
+        d[0].images_mem = [np.array(d[0].images_mem[0], subok=True)]          # a copy: twin gone, bytes never existed
+        with pytest.raises(RuntimeError, match="device-only crop"):
+            model.associate_embeddings(h, d, dists, 11, 5, True, False, extra_kalman_candidates=k, normalize_ims=True)
+    finally:
+        model.device_only_crops = False

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end BUSCA step inside a simulated tracker: crops cut on the GPU, device-resident track memory, centre
-distances, associate_embeddings.  python tools/e2e_sim.py [lost] [dets] [proposals] [d] [precision] [frames]"""
+distances, associate_embeddings.  python tools/e2e_sim.py [lost] [objects] [proposals] [d] [precision] [frames] [device_only]"""
 import os, sys, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,10 +10,11 @@ from busca_amd.sim import SimScene
 from busca_amd.tracking import center_distance
 
 
-def run(lost=32, n_obj=150, P=5, d=512, precision="f16", frames=30, verbose=True):
+def run(lost=32, n_obj=150, P=5, d=512, precision="f16", frames=30, verbose=True, device_only_crops=False):
     args = types.SimpleNamespace(num_layer=4, nhead=4, dim_embedding=512, trans_dim=d, ff_size=2 * d, activation="gelu", dropout_p=0.1,
                                  input_flavour="MEM-SEP-CAN-BAD", output_flavour="CAN", encode_separator_as_reference=True,
-                                 encode_special_tokens=False, reid_weights_file="no", device=torch.device("cuda:0"), precision=precision, seed=7)
+                                 encode_special_tokens=False, reid_weights_file="no", device=torch.device("cuda:0"), precision=precision, seed=7,
+                                 device_only_crops=device_only_crops)
     model = BUSCA(args).to(torch.device("cuda:0")).eval()
     scene = SimScene(model, n_objects=n_obj)
     scene.warm_up(12)
@@ -36,7 +37,7 @@ def run(lost=32, n_obj=150, P=5, d=512, precision="f16", frames=30, verbose=True
                p50_assoc_latency_ms=float(np.percentile(t_assoc, 50) * 1e3), p50_crop_ms=float(np.percentile(t_crop, 50) * 1e3),
                p50_center_distance_ms=float(np.percentile(t_dist, 50) * 1e3),
                busca_frames_per_s=float(1.0 / np.mean(np.array(t_assoc) + np.array(t_dist))),
-               device_resident_crops=model.last_gather[1] == 0)
+               device_resident_crops=model.last_gather[1] == 0, device_only_crops=device_only_crops)
     if verbose:
         print(res)
     return res
@@ -45,4 +46,4 @@ def run(lost=32, n_obj=150, P=5, d=512, precision="f16", frames=30, verbose=True
 if __name__ == "__main__":
     a = sys.argv[1:]
     run(int(a[0]) if a else 32, int(a[1]) if len(a) > 1 else 150, int(a[2]) if len(a) > 2 else 5, int(a[3]) if len(a) > 3 else 512,
-        a[4] if len(a) > 4 else "f16", int(a[5]) if len(a) > 5 else 30)
+        a[4] if len(a) > 4 else "f16", int(a[5]) if len(a) > 5 else 30, device_only_crops=len(a) > 6 and a[6] == "device_only")
