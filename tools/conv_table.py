@@ -7,7 +7,7 @@ from busca_amd import synth
 db, n = sys.argv[1], int(sys.argv[2])
 direct = '--direct' in sys.argv
 con = sqlite3.connect(db)
-rows = con.execute("select name, start, end from kernels where name like '%conv_gemm%' or name like '%conv3x3_halo%' order by start").fetchall()
+rows = con.execute("select name, start, end from kernels where name like '%conv_gemm%' or name like '%conv3x3_halo%' or name like '%stem_halo%' order by start").fetchall()
 specs = synth.reid_conv_specs()
 def osz(h, w, k, s, p): return ((h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1)
 out = []
