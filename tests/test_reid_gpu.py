@@ -145,3 +145,22 @@ def test_reid_halo_conv_path(ctx, monkeypatch):
     assert (halo * generic).sum(1).min() >= 0.9998
     monkeypatch.delenv("BUSCA_REID_HALO")
     ReIDEncoderHIP(ctx, sd)
+
+
+def test_reid_fused_tail_conv1_path(ctx, monkeypatch):
+    """Large batches: layer-1 block tails also run the next bottleneck's conv1 on the tile they hold (tail_conv1_kernel).
+    The stored tensors are rounded exactly as in the two-kernel schedule; only statistics summation order differs."""
+    from busca_amd.reid import ReIDEncoderHIP
+    sd = synth.reid_state_dict(3)
+    n = 40                                           # layer 1 has 122 880 pixels: Gram schedule active, fused tails active
+    crops = _crops(1200, n)
+    monkeypatch.setenv("BUSCA_REID_FUSE_C1", "0")
+    plain = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
+    monkeypatch.setenv("BUSCA_REID_FUSE_C1", "1")
+    m = ReIDEncoderHIP(ctx, sd)
+    fused = m.forward(crops).cpu().numpy()
+    assert np.array_equal(fused, m.forward(crops).cpu().numpy())
+    assert np.abs(fused - plain).max() <= 5e-3, np.abs(fused - plain).max()
+    assert (fused * plain).sum(1).min() >= 0.9998
+    monkeypatch.delenv("BUSCA_REID_FUSE_C1")
+    ReIDEncoderHIP(ctx, sd)
