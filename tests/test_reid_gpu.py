@@ -148,11 +148,12 @@ def test_reid_halo_conv_path(ctx, monkeypatch):
 
 
 def test_reid_fused_tail_conv1_path(ctx, monkeypatch):
-    """Large batches: layer-1 block tails also run the next bottleneck's conv1 on the tile they hold (tail_conv1_kernel).
-    The stored tensors are rounded exactly as in the two-kernel schedule; only statistics summation order differs."""
+    """Large batches: layer-1 and layer-2 block tails also run the next bottleneck's conv1 on the tile they hold
+    (tail_conv1_kernel; all five instantiations are active from 86 crops).  The stored tensors are rounded exactly as in the
+    two-kernel schedule; only statistics summation order differs."""
     from busca_amd.reid import ReIDEncoderHIP
     sd = synth.reid_state_dict(3)
-    n = 40                                           # layer 1 has 122 880 pixels: Gram schedule active, fused tails active
+    n = 96
     crops = _crops(1200, n)
     monkeypatch.setenv("BUSCA_REID_FUSE_C1", "0")
     plain = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
