@@ -148,20 +148,22 @@ def test_reid_halo_conv_path(ctx, monkeypatch):
 
 
 def test_reid_fused_tail_conv1_path(ctx, monkeypatch):
-    """Large batches: layer-1 and layer-2 block tails also run the next bottleneck's conv1 on the tile they hold
-    (tail_conv1_kernel; all five instantiations are active from 86 crops).  The stored tensors are rounded exactly as in the
-    two-kernel schedule; only statistics summation order differs."""
+    """Large batches: the block tails of layers 1-3 also run the next bottleneck's conv1 on the tile they hold
+    (tail_conv1_kernel; with the Gram schedule forced on, all seven instantiations run at 96 crops).  The stored tensors
+    are rounded exactly as in the two-kernel schedule; only statistics summation order differs."""
     from busca_amd.reid import ReIDEncoderHIP
     sd = synth.reid_state_dict(3)
     n = 96
     crops = _crops(1200, n)
+    monkeypatch.setenv("BUSCA_REID_GRAM", "1")
     monkeypatch.setenv("BUSCA_REID_FUSE_C1", "0")
     plain = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
-    monkeypatch.setenv("BUSCA_REID_FUSE_C1", "1")
+    monkeypatch.setenv("BUSCA_REID_FUSE_C1", "3")             # through layer 3 (the default stops at layer 2)
     m = ReIDEncoderHIP(ctx, sd)
     fused = m.forward(crops).cpu().numpy()
     assert np.array_equal(fused, m.forward(crops).cpu().numpy())
     assert np.abs(fused - plain).max() <= 5e-3, np.abs(fused - plain).max()
     assert (fused * plain).sum(1).min() >= 0.9998
     monkeypatch.delenv("BUSCA_REID_FUSE_C1")
+    monkeypatch.delenv("BUSCA_REID_GRAM")
     ReIDEncoderHIP(ctx, sd)
