@@ -166,9 +166,15 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev):
     boxes = synth.dt_inputs(7, B, L, P)
     mb, cb = torch.from_numpy(boxes["mem_boxes"]).to(dev), torch.from_numpy(boxes["can_boxes"]).to(dev)
 
-    def one():
+    side = torch.cuda.Stream(dev)
+
+    def one():                                           # as BUSCA._reid_pair: the two BN batches run on two streams
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            cf = reid.forward(can, stream=side.cuda_stream).view(B, P, -1)
         mf = reid.forward(mem).view(B, L, -1)
-        cf = reid.forward(can).view(B, P, -1)
+        cur.wait_stream(side)
         return dt_model.forward(mf, cf, mb, cb)
 
     one()
