@@ -48,7 +48,11 @@ def reid_forward(sd, x, return_stages=False):
 
 
 def crops_to_reid_input(crops_u8_bgr):
-    """u8 [n,384,128,3] BGR -> float32 [n,3,384,128] RGB normalised (network.py:470-478, 397)."""
+    """u8 [n,384,128,3] BGR -> float32 [n,3,384,128] RGB normalised (network.py:470-478, 397).
+    The reference builds this tensor as `batch[..., [2, 1, 0]].permute(0, 1, 4, 2, 3)` and `.view(-1, C, H, W)`
+    (network.py:397,188): an NHWC buffer seen as NCHW, i.e. torch's channels_last memory format, which the conv /
+    batch-norm kernels then keep for the whole ResNet.  The same strides are produced here; with them the oracle's
+    features are BIT-IDENTICAL to the reference's on the same host (a contiguous NCHW input differs by ~1e-5)."""
     from .geometry import normalize_bgr
-    x = normalize_bgr(np.asarray(crops_u8_bgr))
-    return np.ascontiguousarray(x[..., ::-1].transpose(0, 3, 1, 2))
+    x = torch.from_numpy(normalize_bgr(np.asarray(crops_u8_bgr))).float()
+    return x[..., [2, 1, 0]].permute(0, 3, 1, 2)

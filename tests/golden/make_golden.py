@@ -4,6 +4,8 @@
 
     python tests/golden/make_golden.py            # all sets
     python tests/golden/make_golden.py dt geom    # selected sets
+    python tests/golden/make_golden.py dt512 assoc512 assoc_select reid_big   # round-2 sets (dt512/assoc512 need ~20 GB RAM;
+                                                                              # not part of the default "all")
 
 The reference needs three import shims here: `cv2` and
 `positional_encodings` stubs from oracle/ref_shims/, and a no-network patch of
@@ -115,6 +117,16 @@ def make_dt(ref):
         ("dt_d256_b8_p16", 256, 512, 8, 11, 16, 7),     # BASELINE configs[0]
         ("dt_d256_b32_p16", 256, 512, 32, 11, 16, 8),   # north-star shape
     ]
+    _run_dt_cases(ref_network, cases)
+
+
+def make_dt512(ref):
+    """cfgR, the shipped model shape (config/*/*/*.yml: d=512, ff=1024, P=5).  Building the reference model at d=512
+    materialises its 211x211x61x512 table (~17 GB of transient host RAM, about a minute)."""
+    _run_dt_cases(ref[0], [("dt_d512_b32_p5", 512, 1024, 32, 11, 5, 9)])
+
+
+def _run_dt_cases(ref_network, cases):
     for name, d, ff, B, L, P, seed in cases:
         model = build_ref_model(ref_network, d, ff)
         sd = synth.dt_state_dict(seed, d=d, ff=ff)
@@ -213,6 +225,31 @@ def make_enc(ref):
     print("wrote enc", {k: v.shape for k, v in out.items()})
 
 
+def make_enc_big(ref):
+    """Bucket indices of 512 tracks x 47 tokens (24k tokens, both dtype modes) computed by the reference: the volume test
+    for the kernel's index arithmetic (an index is right or wrong, there is no tolerance)."""
+    _, _, ref_enc = ref
+    d = 12
+    pe = ref_enc.PositionalEncoding(d, input_flavour="MEM-SEP-CAN-BAD", dropout=0.1, encode_sep_as_ref=True,
+                                    batch_first=True, device="cpu")
+    B, L, P = 512, 11, 16
+    inp = synth.dt_inputs(77, B, L, P, sentinel_every=16)
+    mb, cb = inp["mem_boxes"], inp["can_boxes"]
+    out = {"B": B, "L": L, "P": P, "seed": 77}
+    mem, can = torch.zeros(B, L, d), torch.zeros(B, 2 * (P + 2), d)
+    for mode, f64 in (("f64", True), ("f32", False)):
+        m = types.SimpleNamespace(pos_encoder=pe)
+        set_fake_dtype(m, f64)
+        mbt, cbt = torch.from_numpy(mb), torch.from_numpy(cb)
+        fakes = pe._insert_fake_bboxes(can=can, can_bboxes=cbt, ref_bbox=mbt[:, -1:, :].clone(), num_candidates=P + 2, encode_sep_as_ref=True)
+        mt, ct = pe._get_temporal_ids(mem=mem, can=can, num_candidates=P + 2)
+        (mxy, msz), (cxy, csz) = pe._get_spatial_ids(mem_bboxes=mbt, can_bboxes=fakes)
+        ids = torch.stack([torch.cat([mxy, cxy], 1), torch.cat([msz, csz], 1), torch.cat([mt, ct], 1)], -1)
+        out["ids_" + mode] = ids.numpy().astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, "enc_big.npz"), **out)
+    print("wrote enc_big", out["ids_f64"].shape)
+
+
 def make_geom(ref):
     ref_network, ref_tracking, _ = ref
     out = {}
@@ -256,13 +293,22 @@ def load_reid_weights(enc, seed):
     enc.model.load_state_dict(full)
 
 
-def make_reid(ref):
+REID_BIG_CASES = ((96, 1096), (200, 1200))
+
+
+def make_reid_big(ref):
+    """Batches large enough for the default large-batch schedule of the HIP extractor (Gram statistics from ~21 crops,
+    halo-resident 3x3 convs and fused tails from 96): the reference's own ReID_Encoder features."""
+    make_reid(ref, cases=REID_BIG_CASES, fname="reid_big.npz")
+
+
+def make_reid(ref, cases=((3, 43), (5, 45)), fname="reid.npz"):
     ref_network = ref[0]
     enc = ref_network.ReID_Encoder(num_classes=299, device=torch.device("cpu"), pretrained_path="no",
                                    use_domain_adaptation=True, trainable=False, use_checkpointing=False)
     load_reid_weights(enc, 3)
     out = {}
-    for n, seed in ((3, 43), (5, 45)):
+    for n, seed in cases:
         crops = smooth_crops(seed, n)
         x = crops.astype(np.float32) / 255.0
         x -= np.array([0.406, 0.456, 0.485])
@@ -270,8 +316,8 @@ def make_reid(ref):
         xt = torch.from_numpy(x).float()[..., [2, 1, 0]].permute(0, 3, 1, 2)
         _, feats = enc(xt)
         out["feats_n%d_seed%d" % (n, seed)] = feats.numpy()
-    np.savez_compressed(os.path.join(OUT, "reid.npz"), **out)
-    print("wrote reid", {k: v.shape for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print("wrote", fname, {k: v.shape for k, v in out.items()})
 
 
 ASSOC_CASES = [("a", [15, 3, 11], 3, True, 5), ("b", [12, 30], 8, True, 5), ("c", [11, 11, 20], 4, False, 5), ("d", [13], 0, True, 5)]
@@ -308,6 +354,67 @@ def make_assoc(ref):
     print("wrote assoc")
 
 
+# (threshold, keep_highest_value) of the one-hot selection (network.py:415-422; StrongSORT tracker.py:332-333, GHOST :757-758)
+ASSOC_SELECT_CASES = [(None, True), (0.0, True), (0.35, False), (0.35, True), (0.6, True), (-1.0, False)]
+
+
+def make_assoc_select(ref):
+    """highest_candidate_minimum_thresh / keep_highest_value of associate_embeddings on scenes a and b (d=64)."""
+    ref_network, ref_tracking, _ = ref
+    d, ff, seed = 64, 128, 17
+    model = build_ref_model(ref_network, d, ff)
+    load_dt_weights(model, synth.dt_state_dict(seed, d=d, ff=ff))
+    model.reid_encoder = ref_network.ReID_Encoder(num_classes=299, device=torch.device("cpu"), pretrained_path="no",
+                                                  use_domain_adaptation=True, trainable=False, use_checkpointing=False)
+    load_reid_weights(model.reid_encoder, seed)
+    set_fake_dtype(model, True)
+    out = {}
+    for ci in (0, 1):
+        name, hist, n_det, kal, P = ASSOC_CASES[ci]
+        tracks, dets, kals = assoc_scene(seed + ci, hist, n_det, kal)
+        dists = ref_tracking.center_distance(np.array([t.tlbr * t.scale for t in tracks]), np.array([x.tlbr * x.scale for x in dets]))
+        for si, (th, keep) in enumerate(ASSOC_SELECT_CASES):
+            with torch.no_grad():
+                pm, _ = model.associate_embeddings(tracks_embeddings=tracks, dets_embeddings=dets, dists_matrix=dists, seq_len=11,
+                                                   num_candidates=P, use_broader_memory=True, select_highest_candidate=True,
+                                                   highest_candidate_minimum_thresh=th, keep_highest_value=keep,
+                                                   extra_kalman_candidates=kals, normalize_ims=True)
+            out["%s_sel%d" % (name, si)] = pm
+        out["%s_dists" % name] = dists
+    np.savez_compressed(os.path.join(OUT, "assoc_select.npz"), **out)
+    print("wrote assoc_select", {k: v.shape for k, v in out.items()})
+
+
+ASSOC512_CASE = ("r", [15, 3, 11, 12, 40, 11], 9, True, 5)
+
+
+def make_assoc512(ref):
+    """associate_embeddings end to end on the SHIPPED model shape (cfgR: d=512, ff=1024, L=11, P=5, Kalman candidates,
+    use_broader_memory) - reference ReID + DT on CPU."""
+    ref_network, ref_tracking, _ = ref
+    d, ff, seed = 512, 1024, 23
+    model = build_ref_model(ref_network, d, ff)
+    load_dt_weights(model, synth.dt_state_dict(seed, d=d, ff=ff))
+    model.reid_encoder = ref_network.ReID_Encoder(num_classes=299, device=torch.device("cpu"), pretrained_path="no",
+                                                  use_domain_adaptation=True, trainable=False, use_checkpointing=False)
+    load_reid_weights(model.reid_encoder, seed)
+    name, hist, n_det, kal, P = ASSOC512_CASE
+    tracks, dets, kals = assoc_scene(seed, hist, n_det, kal)
+    dists = ref_tracking.center_distance(np.array([t.tlbr * t.scale for t in tracks]), np.array([x.tlbr * x.scale for x in dets]))
+    out = {"%s_dists" % name: dists}
+    for mode, f64 in (("f64", True), ("f32", False)):
+        set_fake_dtype(model, f64)
+        for sel in (True, False):
+            with torch.no_grad():
+                pm, rel = model.associate_embeddings(tracks_embeddings=tracks, dets_embeddings=dets, dists_matrix=dists, seq_len=11,
+                                                     num_candidates=P, use_broader_memory=True, select_highest_candidate=sel,
+                                                     extra_kalman_candidates=kals, normalize_ims=True)
+            out["%s_probs_%s_sel%d" % (name, mode, int(sel))] = pm
+            out["%s_reliable" % name] = rel
+    np.savez_compressed(os.path.join(OUT, "assoc512.npz"), **out)
+    print("wrote assoc512", pm.shape, rel)
+
+
 def make_track(ref):
     """Kalman prediction of STrack.multi_predict (byte_tracker.py:50-61) through the reference's vendored KalmanFilter
     (adapters/CenterTrack/src/lib/utils/mot_online/kalman_filter.py, the adapter's fallback import)."""
@@ -342,7 +449,12 @@ def main():
     ref = import_reference()
     if "dt" in which:
         make_dt(ref)
-    for name in ("enc", "geom", "assoc", "reid", "track"):
+    if "dt512" in which:
+        make_dt512(ref)
+    if "assoc512" in which:
+        make_assoc512(ref)
+        _MODELS.pop((512, 1024), None)
+    for name in ("enc", "enc_big", "geom", "assoc", "assoc_select", "reid", "reid_big", "track"):
         fn = globals().get("make_" + name)
         if name in which and fn is not None:
             fn(ref)

@@ -176,3 +176,58 @@ def test_device_only_crops(model):
             model.associate_embeddings(h, d, dists, 11, 5, True, False, extra_kalman_candidates=k, normalize_ims=True)
     finally:
         model.device_only_crops = False
+
+
+def _model(d, ff, seed, precision="f32", reid_precision="f16"):
+    from busca_amd.network import BUSCA
+    a = _args(d=d, ff=ff, precision=precision)
+    a.reid_precision = reid_precision
+    m = BUSCA(a).to(torch.device("cuda:0")).eval()
+    sd = dict(synth.dt_state_dict(seed, d=d, ff=ff))
+    sd.update({"reid_encoder.model." + k: v for k, v in synth.reid_state_dict(seed).items()})
+    m.load_state_dict(sd)
+    return m
+
+
+def test_associate_selection_thresholds_vs_reference(golden_dir):
+    """highest_candidate_minimum_thresh / keep_highest_value (network.py:415-422; passed by StrongSORT tracker.py:332-333 and
+    GHOST tracker.py:757-758) against the reference's outputs (tests/golden/assoc_select.npz), exact flavours."""
+    import make_golden as mg
+    m = _model(64, 128, 17, "f32", "f32")
+    g = np.load(os.path.join(golden_dir, "assoc_select.npz"))
+    for ci in (0, 1):
+        name, tracks, dets, kals, P = _case(ci)
+        for si, (th, keep) in enumerate(mg.ASSOC_SELECT_CASES):
+            pm, _ = m.associate_embeddings(tracks, dets, g[name + "_dists"], 11, P, True, True, highest_candidate_minimum_thresh=th,
+                                           keep_highest_value=keep, extra_kalman_candidates=kals, normalize_ims=True)
+            ref = g["%s_sel%d" % (name, si)]
+            assert np.array_equal(pm == 0, ref == 0), (name, si)          # same winners pass / fail the threshold
+            assert np.abs(pm - ref).max() <= 2e-4, (name, si, np.abs(pm - ref).max())
+
+
+@pytest.mark.parametrize("flavour", ["exact", "fast"])
+def test_associate_shipped_shape_vs_reference(golden_dir, flavour):
+    """cfgR - the shape every shipped config runs (d=512, ff=1024, L=11, P=5, Kalman candidates, broader memory) - end to end
+    against the reference's associate_embeddings (tests/golden/assoc512.npz): exact flavours to float32 round-off with
+    identical decisions; default fast flavours (f16 DT operands, fp16 ReID) within the fp16 tolerance."""
+    import make_golden as mg
+    g = np.load(os.path.join(golden_dir, "assoc512.npz"))
+    name, hist, n_det, kal, P = mg.ASSOC512_CASE
+    tracks, dets, kals = mg.assoc_scene(23, hist, n_det, kal)
+    m = _model(512, 1024, 23, "f32", "f32") if flavour == "exact" else _model(512, 1024, 23, "f16", "f16")
+    tol = 1e-3 if flavour == "exact" else 6e-2          # d=512 amplifies feature round-off ~10x (see test_oracle_golden.py)
+    for mode in ("f64", "f32"):
+        m.pinned_numpy = (mode == "f64")
+        m._dirty = True
+        pm, rel = m.associate_embeddings(tracks, dets, g[name + "_dists"], 11, P, True, False, extra_kalman_candidates=kals, normalize_ims=True)
+        ref = g["%s_probs_%s_sel0" % (name, mode)]
+        assert np.array_equal(rel, g[name + "_reliable"])
+        assert np.array_equal(pm == 0, ref == 0)
+        assert np.abs(pm - ref).max() <= tol, np.abs(pm - ref).max()
+        pm1, _ = m.associate_embeddings(tracks, dets, g[name + "_dists"], 11, P, True, True, extra_kalman_candidates=kals, normalize_ims=True)
+        ref1 = g["%s_probs_%s_sel1" % (name, mode)]
+        full = m._last["probs"].cpu().numpy()
+        srt = np.sort(full, axis=-1)
+        clear = (srt[:, -1] - srt[:, -2]) > 2 * tol
+        assert clear.sum() > 0
+        assert np.array_equal(pm1[clear], ref1[clear])

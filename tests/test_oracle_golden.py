@@ -84,6 +84,16 @@ def test_bucket_ids_match_reference(golden_dir, mode):
     assert bad_xy == (100 if mode == "f64" else 2)
 
 
+@pytest.mark.parametrize("mode", ["f64", "f32"])
+def test_bucket_ids_volume_match_reference(golden_dir, mode):
+    """24k tokens (512 tracks x 47) against the reference's own indices: every index identical."""
+    from oracle import encoding as enc
+    g = np.load(os.path.join(golden_dir, "enc_big.npz"))
+    inp = synth.dt_inputs(int(g["seed"]), int(g["B"]), int(g["L"]), int(g["P"]), sentinel_every=16)
+    ids = enc.token_bucket_ids(inp["mem_boxes"], inp["can_boxes"], fake_f64=(mode == "f64")).numpy()
+    assert np.array_equal(ids, g["ids_" + mode].astype(np.int64))
+
+
 # ---- geometry -----------------------------------------------------------------------------------------
 def test_geometry_matches_reference(golden_dir):
     from oracle import geometry as og
@@ -144,7 +154,19 @@ def test_reid_oracle_matches_reference(golden_dir):
     sd = synth.reid_state_dict(3)
     crops = smooth_crops(43, 3)
     got = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
-    np.testing.assert_allclose(got, g["feats_n3_seed43"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got, g["feats_n3_seed43"], rtol=0, atol=2e-6)
+
+
+def test_reid_oracle_matches_reference_large_batch(golden_dir):
+    """96-crop BN batch (the size from which the HIP extractor's large-batch schedule is fully active)."""
+    from oracle import reid as oreid
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import smooth_crops
+    g = np.load(os.path.join(golden_dir, "reid_big.npz"))
+    sd = synth.reid_state_dict(3)
+    got = oreid.reid_forward(sd, oreid.crops_to_reid_input(smooth_crops(1096, 96))).numpy()
+    np.testing.assert_allclose(got, g["feats_n96_seed1096"], rtol=0, atol=2e-6)      # bit-identical on the generating host
 
 
 # ---- associate_embeddings end to end (reference ReID + DT + host logic) ------------------------------------
@@ -184,3 +206,57 @@ def test_associate_early_returns():
     from oracle import associate as oa
     assert oa.associate_embeddings(None, [], [1], None, 11, 5, True, True) == (None, None)
     assert oa.associate_embeddings(None, [1], [], None, 11, 5, True, True) == (None, None)
+
+
+def _oracle_step(seed, d, ff, fake_f64=True):
+    import torch
+    from oracle import reid as oreid
+    sd_dt, sd_reid = synth.dt_state_dict(seed, d=d, ff=ff), synth.reid_state_dict(seed)
+    cfg = odt.DTConfig(d=d, ff=ff, fake_f64=fake_f64)
+
+    def step(mem_u8, can_u8, mem_ltrb, can_ltrb):
+        B, L = mem_u8.shape[:2]
+        P_ = can_u8.shape[1]
+        mf = oreid.reid_forward(sd_reid, oreid.crops_to_reid_input(mem_u8.reshape(B * L, 384, 128, 3))).view(B, L, -1)
+        cf = oreid.reid_forward(sd_reid, oreid.crops_to_reid_input(can_u8.reshape(B * P_, 384, 128, 3))).view(B, P_, -1)
+        return torch.softmax(odt.dt_forward(sd_dt, cfg, mf, cf, mem_ltrb, can_ltrb), -1).numpy()
+    return step
+
+
+def test_associate_selection_thresholds_match_reference(golden_dir):
+    """highest_candidate_minimum_thresh / keep_highest_value (network.py:415-422; StrongSORT tracker.py:332-333)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    from oracle import associate as oa
+    g = np.load(os.path.join(golden_dir, "assoc_select.npz"))
+    name, tracks, dets, kals, P = _assoc_case(0)
+    cache = {}
+
+    def step(*a):                       # the network output does not depend on the selection mode: compute it once
+        if "p" not in cache:
+            cache["p"] = _oracle_step(17, 64, 128)(*a)
+        return cache["p"]
+    kinds = set()
+    for si, (th, keep) in enumerate(mg.ASSOC_SELECT_CASES):
+        pm, _ = oa.associate_embeddings(step, tracks, dets, g[name + "_dists"], 11, P, True, True, highest_candidate_minimum_thresh=th,
+                                        keep_highest_value=keep, extra_kalman_candidates=kals)
+        ref = g["%s_sel%d" % (name, si)]
+        assert np.array_equal(pm == 0, ref == 0)
+        np.testing.assert_allclose(pm, ref, rtol=0, atol=5e-5)
+        kinds.add((bool((ref > 0).any()), bool(((ref > 0) & (ref < 1)).any())))
+    assert len(kinds) >= 2              # the cases really exercise pass / fail / keep-value
+
+
+def test_associate_shipped_shape_matches_reference(golden_dir):
+    """cfgR (d=512, ff=1024, P=5, Kalman candidates, broader memory): oracle == reference, both dtype modes."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    from oracle import associate as oa
+    g = np.load(os.path.join(golden_dir, "assoc512.npz"))
+    name, hist, n_det, kal, P = mg.ASSOC512_CASE
+    tracks, dets, kals = mg.assoc_scene(23, hist, n_det, kal)
+    pm, rel = oa.associate_embeddings(_oracle_step(23, 512, 1024), tracks, dets, g[name + "_dists"], 11, P, True, False, extra_kalman_candidates=kals)
+    assert np.array_equal(rel, g[name + "_reliable"])
+    np.testing.assert_allclose(pm, g[name + "_probs_f64_sel0"], rtol=0, atol=5e-5)

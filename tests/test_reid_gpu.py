@@ -100,6 +100,43 @@ def test_reid_golden_reference_features(ctx, golden_dir):
         assert ((got16 * ref).sum(1) >= COS_MIN).all()
 
 
+@pytest.mark.parametrize("n,seed", [(96, 1096), (200, 1200)])
+def test_reid_default_large_batch_schedule_vs_reference(ctx, golden_dir, monkeypatch, n, seed):
+    """The DEFAULT schedule at batch sizes where all of it is active (Gram-matrix statistics + fused downsample, halo-resident
+    3x3 convs, one-kernel stem, block tails fused with the next conv1) against features computed by the reference's own
+    ReID_Encoder (tests/golden/reid_big.npz): fp16 flavour within the stated fp16 tolerance, exact-f32 flavour <= 5e-5."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import smooth_crops
+    from busca_amd.reid import ReIDEncoderHIP
+    for k in ("BUSCA_REID_GRAM", "BUSCA_REID_HALO", "BUSCA_REID_FUSE_C1", "BUSCA_REID_SPLITK_BLOCKS", "BUSCA_REID_DIRECT_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    ref = np.load(os.path.join(golden_dir, "reid_big.npz"))["feats_n%d_seed%d" % (n, seed)]
+    sd = synth.reid_state_dict(3)
+    crops = smooth_crops(seed, n)
+    got16 = ReIDEncoderHIP(ctx, sd, precision="f16").forward(crops).cpu().numpy()
+    cos = (got16 * ref).sum(1)
+    assert cos.min() >= COS_MIN, cos.min()
+    assert np.abs(got16 - ref).max() <= FEAT_ATOL, np.abs(got16 - ref).max()
+    got32 = ReIDEncoderHIP(ctx, sd, precision="f32").forward(crops).cpu().numpy()
+    assert np.abs(got32 - ref).max() <= 5e-5, np.abs(got32 - ref).max()
+
+
+@pytest.mark.parametrize("n", [352, 512])
+def test_reid_benchmarked_batches_vs_oracle(ctx, n):
+    """The batch sizes bench.py's full_step times (32 x 11 memory crops, 32 x 16 candidate crops): fp16 default schedule vs
+    the float32 oracle run on this host."""
+    from busca_amd.reid import ReIDEncoderHIP
+    from oracle import reid as oreid
+    sd = synth.reid_state_dict(3)
+    crops = _crops(2000 + n, n)
+    got = ReIDEncoderHIP(ctx, sd, precision="f16").forward(crops).cpu().numpy()
+    ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
+    cos = (got * ref).sum(1)
+    assert cos.min() >= COS_MIN, cos.min()
+    assert np.abs(got - ref).max() <= FEAT_ATOL, np.abs(got - ref).max()
+
+
 @pytest.mark.parametrize("n", [5, 24])
 def test_reid_gram_statistics_path(ctx, monkeypatch, n):
     """Large batches take BN3 / downsample-BN statistics from the Gram matrix of the conv's input and fuse the downsample
