@@ -86,6 +86,15 @@ def cpu_baseline(sd, cfg_kw, inp, budget_s):
                        % (n, el, best, {k: round(v, 1) for k, v in sweep.items()}))
 
 
+def split_steps(k, F):
+    """k steps as ceil(k/F) launches of near-equal size (20 steps, F = 8 -> 7 + 7 + 6, never a half-empty 8 + 8 + 4)."""
+    if k <= 0:
+        return []
+    n = -(-k // F)
+    base, extra = divmod(k, n)
+    return [base + 1] * extra + [base] * (n - extra)
+
+
 class DTRunner:
     """F steps worth of synthetic tracks resident in HBM + one loaded Decision-Transformer flavour."""
 
@@ -101,30 +110,30 @@ class DTRunner:
         self.stream = torch.cuda.current_stream(dev).cuda_stream
 
     def launch(self, nsteps):
+        self.model._ensure_loaded()
         t, lib = self.t, self.ctx.lib
         self.ctx.check(lib.busca_dt_forward(self.ctx.h, t["mem_feat"].data_ptr(), t["can_feat"].data_ptr(),
                                             t["mem_boxes"].data_ptr(), t["can_boxes"].data_ptr(), self.B * nsteps, self.L, self.P,
                                             self.logits.data_ptr(), self.probs.data_ptr(), self.amax.data_ptr(), None, None, self.stream))
 
     def run_steps(self, k):
-        full, rem = divmod(k, self.F)
-        for _ in range(full):
-            self.launch(self.F)
-        if rem:
-            self.launch(rem)
-        return full + (1 if rem else 0)
+        sizes = split_steps(k, self.F)
+        for n in sizes:
+            self.launch(n)
+        return len(sizes)
 
-    def kernel_avg_ms(self, k):
-        """Average kernel duration from HIP events recorded around every launch on the launch stream."""
+    def kernel_time(self, k):
+        """(total kernel ms, kernel launches, forward calls, steps) of k steps, from HIP events recorded around every kernel
+        launch on the launch stream (busca_timing_*).  The fused path is one kernel per call; the layer-wise path several."""
         lib, h = self.ctx.lib, self.ctx.h
         lib.busca_timing_read(h, None, None, 1)
         lib.busca_timing_enable(h, 1)
-        self.run_steps(k)
+        calls = self.run_steps(k)
         torch.cuda.synchronize(self.dev)
         avg, n = C.c_double(0), C.c_int64(0)
         lib.busca_timing_read(h, C.byref(avg), C.byref(n), 1)
         lib.busca_timing_enable(h, 0)
-        return avg.value, n.value
+        return avg.value * n.value, n.value, calls, k
 
     def p50_latency_ms(self, samples):
         if samples <= 0:
@@ -141,20 +150,48 @@ class DTRunner:
         return float(np.percentile(np.array(lat), 50) * 1e3)
 
 
-def roofline_obj(precision, B, L, P, d, ff, steps_per_launch, kern_ms, bracket_ms):
-    flops = dt_step_flops(B * steps_per_launch, L, P, d, ff)
-    ach = flops / (kern_ms * 1e-3) / 1e12
+def roofline_obj(precision, B, L, P, d, ff, timing, bracket_ms_per_call, kernel="dt_fused_kernel"):
+    """timing = DTRunner.kernel_time(...).  achieved = algorithmic FLOPs of the steps those launches REALLY processed / the
+    kernel time they took (a 6-step launch counts 6 steps)."""
+    tot_ms, nk, calls, steps = timing
+    flops = dt_step_flops(B, L, P, d, ff) * steps
+    ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else float("nan")
+    spl = steps / max(1, calls)
     traffic = None
     try:    # HBM bytes per launch from the committed PMC run (profiles/pmc_traffic.json), same workload and F
         meta = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        ent = meta.get("dt_%s_F%d_B%d_P%d_d%d" % (precision, steps_per_launch, B, P, d))
+        ent = meta.get("dt_%s_F%d_B%d_P%d_d%d" % (precision, int(round(spl)), B, P, d))
         traffic = ent["hbm_bytes_per_launch"] if ent else None
     except Exception:
         traffic = None
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[precision],
-            "traffic": traffic, "kernel": "dt_fused_kernel", "kernel_avg_ms": kern_ms, "flops_per_launch": flops,
-            "steps_per_launch": steps_per_launch, "event_bracket_ms_per_launch": bracket_ms,
+            "traffic": traffic, "kernel": kernel, "kernel_avg_ms": tot_ms / max(1, nk), "kernel_launches_per_call": nk / max(1, calls),
+            "kernel_ms_per_call": tot_ms / max(1, calls), "flops_per_call": flops / max(1, calls),
+            "steps_per_launch": spl, "event_bracket_ms_per_launch": bracket_ms_per_call,
             "algorithmic_bytes_per_step": dt_step_bytes(B, L, P, d, ff)}
+
+
+def config_leg(ctx, dev, name, B, L, P, d, precision, F, steps, seed=7):
+    """One BASELINE config as its own DT-step measurement (outside the contract's timed region): value + roofline."""
+    ff = 2 * d
+    sd = synth.dt_state_dict(seed, d=d, ff=ff)
+    big = synth.dt_inputs(seed, B * F, L, P)
+    tens = {k: torch.from_numpy(v).to(dev) for k, v in big.items()}
+    run = DTRunner(ctx, sd, precision, tens, B, L, P, F, dev)
+    run.run_steps(max(F, steps // 10))
+    torch.cuda.synchronize(dev)
+    a = time.perf_counter()
+    calls = run.run_steps(steps)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - a
+    timing = run.kernel_time(min(steps, 20 * F))
+    T = L + 2 * (P + 2)
+    fused = timing[1] == timing[2]
+    return {"workload": "%s DT-step: %d lost x %d proposals x d%d (L=%d, T=%d, ff=%d)" % (name, B, P, d, L, T, ff), "dtype": precision,
+            "value": steps / el, "unit": "steps/s", "steps": steps, "ms_per_step": el / steps * 1e3, "steps_in_flight_per_launch": F,
+            "path": "fused (one kernel per call)" if fused else "layer-wise (%d kernels per call)" % round(timing[1] / max(1, timing[2])),
+            "roofline": roofline_obj(precision, B, L, P, d, ff, timing, el / calls * 1e3,
+                                     kernel="dt_fused_kernel" if fused else "dtl_gemm_kernel + dtl_attention_kernel (whole forward)")}
 
 
 def full_step(ctx, dt_model, B, L, P, n_steps, dev):
@@ -268,14 +305,21 @@ def main():
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     ev_ms = ev0.elapsed_time(ev1)
     elapsed = sharding.max_over_ranks(elapsed, dist, dev)
+    # who was live: every rank reports (rank, device index, device name, library version, its own elapsed time)
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev),
+          "busca_version": int(ctx.lib.busca_version()), "elapsed_s": my_elapsed, "steps": args.steps}
+    ranks = [me]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
 
     # ---- roofline leg: the same launches, each bracketed by HIP events on the launch stream -------------------
-    spl = F if args.steps >= F else args.steps
-    kern_ms, nl = run.kernel_avg_ms(min(args.steps, 50 * F))
-    if not nl:
-        kern_ms = ev_ms / max(1, n_launch)
+    timing = run.kernel_time(min(args.steps, 50 * F))
+    if not timing[1]:
+        timing = (ev_ms, n_launch, n_launch, args.steps)
     p50 = run.p50_latency_ms(args.latency_samples)
 
     result = None
@@ -291,7 +335,8 @@ def main():
                                    "precomputed; BASELINE.json configs[1]-shaped batch without the tracker" % (B, P, d, L, L + 2 * (P + 2), ff),
                        "lost": B, "proposals": P, "d": d, "seq_len": L, "steps_in_flight_per_launch": F,
                        "parallelism": "independent sequences sharded per GPU, no collective (%d rank%s)" % (world, "" if world == 1 else "s")},
-            "roofline": roofline_obj(args.precision, B, L, P, d, ff, spl, kern_ms, ev_ms / max(1, n_launch)),
+            "roofline": roofline_obj(args.precision, B, L, P, d, ff, timing, ev_ms / max(1, n_launch)),
+            "ranks": ranks,
         }
     # ---- secondary precision + full step (rank 0, outside the contract's timed region) ---------------------------
     if rank == 0 and not args.no_variants:
@@ -304,10 +349,23 @@ def main():
         nl2 = r2.run_steps(k2)
         torch.cuda.synchronize(dev)
         el2 = time.perf_counter() - a
-        km2, n2 = r2.kernel_avg_ms(min(k2, 50 * F))
+        tm2 = r2.kernel_time(min(k2, 50 * F))
+        if not tm2[1]:
+            tm2 = (el2 * 1e3, nl2, nl2, k2)
         result["variants"] = {other: {"value": k2 / el2, "unit": "steps/s", "steps": k2, "n_gpus": 1, "dtype": other,
                                       "p50_latency_ms": r2.p50_latency_ms(min(args.latency_samples, 300)),
-                                      "roofline": roofline_obj(other, B, L, P, d, ff, min(F, k2), km2 if n2 else el2 / nl2 * 1e3, el2 / nl2 * 1e3)}}
+                                      "roofline": roofline_obj(other, B, L, P, d, ff, tm2, el2 / nl2 * 1e3)}}
+        # the other BASELINE shapes as their own DT-step lines (cfgR = shipped model shape; cfg4 = BASELINE configs[3];
+        # cfg5 = BASELINE configs[4], one GPU's share is the full 512-track step here)
+        cfgs = {}
+        for name, cB, cP, cd, prec, cF, csteps in (("cfgR", 32, 5, 512, "f32", 8, 400), ("cfgR_f16", 32, 5, 512, "f16", 8, 800),
+                                                   ("cfg4", 128, 32, 512, "f32", 2, 20), ("cfg4_f16", 128, 32, 512, "f16", 2, 60),
+                                                   ("cfg5", 512, 64, 512, "f16", 1, 20)):
+            try:
+                cfgs[name] = config_leg(ctx, dev, name, cB, L, cP, cd, prec, cF, csteps)
+            except Exception as e:
+                cfgs[name] = {"error": repr(e)}
+        result["configs"] = cfgs
         if args.full_steps > 0:
             f16_model = r2.model if other == "f16" else DTRunner(ctx, sd, "f16", tens, B, L, P, 1, dev).model
             result["full_step"] = full_step(ctx, f16_model, B, L, P, args.full_steps, dev)

@@ -1,0 +1,122 @@
+"""Device-resident track memory: a bounded pool of crop slots in HBM.
+
+The reference keeps every crop a track has ever produced in per-track Python lists of host arrays
+(`STrack.images_mem`, adapters/ByteTrack/yolox/tracker/byte_tracker.py:40-42,90-94,117-121; never trimmed - GHOST
+works around the growth with `avoid_memory_leak`, adapters/GHOST/src/tracker.py:249-258) and ships B*(L+P) of them to
+the device every frame.  Here `get_image_crops` writes each crop straight into a slot of this pool and hands the tracker
+an object that remembers its slot; `associate_embeddings` then gathers slots with one index-gather kernel
+(busca_gather_crops).
+
+Lifetime and bound:
+  * a slot belongs to exactly one crop; it returns to the free list when the LAST Python reference to that crop dies
+    (track removed, list trimmed) - eviction follows track lifetime, no bookkeeping in the tracker;
+  * the pool grows slab by slab up to `budget_bytes` (BUSCA_CROP_POOL_MB, default 16 GiB of the 288 GB); beyond that the
+    OLDEST live crops are spilled: their bytes move to host memory (already there unless `device_only_crops`) and their
+    slot is reused.  A spilled crop keeps working through the host path of `associate_embeddings` (bit-identical).
+HBM use is therefore flat once the budget is reached, whatever the sequence length.
+"""
+import os
+import weakref
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+CROP_H, CROP_W = 384, 128
+CROP_BYTES = CROP_H * CROP_W * 3
+
+
+class Slot:
+    """One live crop of the pool.  `ptr` is its device address (0 once spilled); `host` its host bytes (None until needed)."""
+    __slots__ = ("pool", "slab", "index", "ptr", "host", "__weakref__")
+
+    def __init__(self, pool, slab, index, ptr):
+        self.pool, self.slab, self.index, self.ptr, self.host = pool, slab, index, ptr, None
+
+    def tensor(self):
+        """cuda u8 [384,128,3] view of the slot, or None after a spill."""
+        return self.pool.slabs[self.slab][self.index] if self.ptr else None
+
+    def host_bytes(self):
+        """uint8 [384,128,3] host copy (device -> host on first use when the crop only lived in HBM)."""
+        if self.host is None:
+            if not self.ptr:
+                raise RuntimeError("crop slot lost both its device and its host copy")       # cannot happen: spill copies first
+            t = self.tensor()
+            self.host = t.cpu().numpy() if t.is_cuda else t.numpy().copy()     # (.cpu() of a host tensor would alias the slot)
+        return self.host
+
+    def __del__(self):
+        try:
+            self.pool._release(self)
+        except Exception:
+            pass
+
+
+class CropPool:
+    def __init__(self, device, budget_bytes=None, slab_crops=512):
+        if budget_bytes is None:
+            budget_bytes = int(float(os.environ.get("BUSCA_CROP_POOL_MB", "16384")) * (1 << 20))
+        self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        self.slab_crops = int(slab_crops)
+        self.max_slabs = max(1, int(budget_bytes) // (self.slab_crops * CROP_BYTES))
+        self.slabs = []
+        self.free = []                      # (slab, index)
+        self.live = OrderedDict()           # id -> weakref(Slot), allocation order = eviction order
+        self.spilled = 0                    # crops moved to the host because the budget was reached
+        self.peak_live = 0
+
+    # ---- accounting ----------------------------------------------------------------------------------------------------
+    @property
+    def capacity(self):
+        return len(self.slabs) * self.slab_crops
+
+    @property
+    def device_bytes(self):
+        return self.capacity * CROP_BYTES
+
+    @property
+    def n_live(self):
+        return len(self.live)
+
+    # ---- allocation ----------------------------------------------------------------------------------------------------
+    def _grow(self):
+        t = torch.empty(self.slab_crops, CROP_H, CROP_W, 3, dtype=torch.uint8, device=self.device)
+        self.slabs.append(t)
+        s = len(self.slabs) - 1
+        self.free.extend((s, i) for i in range(self.slab_crops - 1, -1, -1))
+
+    def _spill_oldest(self, k):
+        """Move the k oldest live crops to the host and reuse their slots."""
+        if k > len(self.live):
+            raise RuntimeError("crop pool budget (%d crops) is smaller than one request" % (self.max_slabs * self.slab_crops))
+        for _ in range(k):
+            _, ref = self.live.popitem(last=False)
+            slot = ref()
+            if slot is None or not slot.ptr:
+                continue
+            slot.host_bytes()
+            self.free.append((slot.slab, slot.index))
+            slot.ptr = 0
+            self.spilled += 1
+
+    def alloc(self, n):
+        """n fresh slots (list of Slot).  Their contents are undefined until a kernel writes them."""
+        while len(self.free) < n:
+            if len(self.slabs) < self.max_slabs:
+                self._grow()
+            else:
+                self._spill_oldest(n - len(self.free))
+        out = []
+        for _ in range(n):
+            s, i = self.free.pop()
+            slot = Slot(self, s, i, self.slabs[s].data_ptr() + i * CROP_BYTES)
+            self.live[id(slot)] = weakref.ref(slot)
+            out.append(slot)
+        self.peak_live = max(self.peak_live, len(self.live))
+        return out
+
+    def _release(self, slot):
+        if self.live.pop(id(slot), None) is not None and slot.ptr:
+            self.free.append((slot.slab, slot.index))
+            slot.ptr = 0

@@ -3,6 +3,8 @@
 Inputs/outputs are torch tensors on the GPU; torch only provides device memory and the stream."""
 import ctypes as C
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -19,14 +21,26 @@ class DecisionTransformerHIP:
         self.d, self.ff, self.nlayers, self.E, self.nhead = d, ff, nl, E, 4
         self.precision = precision
         self.cfg = _lib.DTCfg(d, ff, 4, nl, E, _ACT[activation], 1 if fake_bbox_f64 else 0, _PREC[precision])
-        blob = weights.dt_blob(state_dict, nl)
+        self._blob = weights.dt_blob(state_dict, nl)
         want = ctx.lib.busca_dt_blob_floats(C.byref(self.cfg))
         if want == 0:
             raise _lib.BuscaError("unsupported Decision-Transformer shape d=%d ff=%d layers=%d E=%d" % (d, ff, nl, E))
-        assert blob.size == want, (blob.size, want)
-        lxy, lsz, lt, c = weights.encoding_luts(d)
-        ctx.check(ctx.lib.busca_dt_load_weights(ctx.h, C.byref(self.cfg), blob.ctypes.data, blob.size,
+        assert self._blob.size == want, (self._blob.size, want)
+        self._luts = weights.encoding_luts(d)
+        self._upload()
+
+    def _upload(self):
+        ctx, (lxy, lsz, lt, c) = self.ctx, self._luts
+        ctx.check(ctx.lib.busca_dt_load_weights(ctx.h, C.byref(self.cfg), self._blob.ctypes.data, self._blob.size,
                                                 lxy.ctypes.data, lsz.ctypes.data, lt.ctypes.data, c))
+        ctx.dt_owner = weakref.ref(self)
+
+    def _ensure_loaded(self):
+        """A busca_ctx holds ONE Decision-Transformer weight set (include/busca_hip.h).  If another handle loaded its
+        own weights into this context since, put this model's back before computing - never run on someone else's."""
+        owner = getattr(self.ctx, "dt_owner", None)
+        if owner is None or owner() is not self:
+            self._upload()
 
     @staticmethod
     def _f32(t, dev):
@@ -36,6 +50,7 @@ class DecisionTransformerHIP:
 
     def forward(self, mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=False, want_att=False, stream=None):
         """-> dict(logits[B,P+2], probs[B,P+2], argmax[B] int32, hidden?[B,T,d], att?[nl,B,4,T,T])."""
+        self._ensure_loaded()
         dev = torch.device("cuda", self.ctx.device)
         mem_feat, can_feat = self._f32(mem_feat, dev), self._f32(can_feat, dev)
         mem_ltrb, can_ltrb = self._f32(mem_ltrb, dev), self._f32(can_ltrb, dev)
@@ -57,6 +72,7 @@ class DecisionTransformerHIP:
         return out
 
     def bucket_ids(self, mem_ltrb, can_ltrb):
+        self._ensure_loaded()
         dev = torch.device("cuda", self.ctx.device)
         mem_ltrb, can_ltrb = self._f32(mem_ltrb, dev), self._f32(can_ltrb, dev)
         B, L, _ = mem_ltrb.shape

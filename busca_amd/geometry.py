@@ -52,21 +52,45 @@ def topk_rows(ctx, dist, P):
     return idx
 
 
-def crop_gather(ctx, frame, boxes, want_u8=True, want_f16=False):
-    """frame: u8 [H,W,3] BGR (numpy or cuda tensor); boxes [n,4] x1y1x2y2 -> (u8 [n,384,128,3] | None,
-    fp16 [n,384,128,4] RGB0 normalised | None), both on the GPU."""
+def crop_pool(ctx):
+    """The context's device crop pool (busca_amd/crop_pool.py), created on first use."""
+    if getattr(ctx, "_crop_pool", None) is None:
+        from .crop_pool import CropPool
+        ctx._crop_pool = CropPool(ctx.device)
+    return ctx._crop_pool
+
+
+def crop_gather(ctx, frame, boxes, want_u8=True, want_f16=False, dst_ptrs=None):
+    """frame: u8 [H,W,3] BGR (numpy or cuda tensor); boxes [n,4] x1y1x2y2 (float: rounded to extents in float64 on the
+    host; int32: already extents) -> (u8 [n,384,128,3] | None, fp16 [n,384,128,4] RGB0 normalised | None) on the GPU.
+    `dst_ptrs` (uint64 [n]): write crop i to that device address instead (crop-pool slots)."""
+    from .tracking import box_extents
     dev = _dev(ctx)
     if not torch.is_tensor(frame):
         frame = torch.from_numpy(np.ascontiguousarray(frame))
     frame = frame.to(dev).contiguous()
     assert frame.dtype == torch.uint8 and frame.dim() == 3 and frame.shape[2] == 3
-    if not torch.is_tensor(boxes):
-        boxes = torch.from_numpy(np.ascontiguousarray(np.asarray(boxes, dtype=np.float32).reshape(-1, 4)))
-    boxes = boxes.to(device=dev, dtype=torch.float32).contiguous()
-    n = boxes.shape[0]
+    if torch.is_tensor(boxes):
+        boxes = boxes.detach().cpu().numpy()
+    boxes = np.asarray(boxes)
+    rects = boxes.reshape(-1, 4) if boxes.dtype == np.int32 else box_extents(boxes)
+    rects_d = torch.from_numpy(np.ascontiguousarray(rects)).to(dev)
+    n = rects.shape[0]
     H, W = frame.shape[:2]
     u8 = torch.empty(n, 384, 128, 3, dtype=torch.uint8, device=dev) if want_u8 else None
     f16 = torch.empty(n, 384, 128, 4, dtype=torch.float16, device=dev) if want_f16 else None
-    ctx.check(ctx.lib.busca_crop_gather(ctx.h, frame.data_ptr(), H, W, frame.stride(0), boxes.data_ptr(), n,
-                                        _lib.ptr(u8), _lib.ptr(f16), _stream(ctx)))
+    dst = torch.from_numpy(np.ascontiguousarray(dst_ptrs).view(np.int64)).to(dev) if dst_ptrs is not None else None
+    ctx.check(ctx.lib.busca_crop_gather_ex(ctx.h, frame.data_ptr(), H, W, frame.stride(0), rects_d.data_ptr(), n,
+                                           _lib.ptr(dst), _lib.ptr(u8), _lib.ptr(f16), _stream(ctx)))
     return u8, f16
+
+
+def gather_crops(ctx, src_ptrs):
+    """uint64 [n] device addresses of 147 456-byte crops (0 = all-zero crop) -> cuda u8 [n,384,128,3] (busca_gather_crops)."""
+    dev = _dev(ctx)
+    n = len(src_ptrs)
+    out = torch.empty(n, 384, 128, 3, dtype=torch.uint8, device=dev)
+    if n:
+        src = torch.from_numpy(np.ascontiguousarray(src_ptrs, dtype=np.uint64).view(np.int64)).to(dev)
+        ctx.check(ctx.lib.busca_gather_crops(ctx.h, src.data_ptr(), n, out.data_ptr(), _stream(ctx)))
+    return out

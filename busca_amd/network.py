@@ -72,7 +72,7 @@ class BUSCA:
         # ReID flavour: "f16" (fp16 activations, fast) or "f32" (exact float32 convs, reference-exact, ~6x slower)
         self.reid_precision = getattr(args, "reid_precision", os.environ.get("BUSCA_AMD_REID_PRECISION", "f16"))
         self.pinned_numpy = bool(getattr(args, "pinned_numpy_semantics", True))
-        # True: get_image_crops(normalize=False) keeps the crops on the GPU only (host arrays are placeholders)
+        # True: get_image_crops(normalize=False) keeps the crops in the device pool only; host reads copy them back on demand
         self.device_only_crops = bool(getattr(args, "device_only_crops", False))
         self.store_logits = False           # set True to fill .logits / .mem_logits like the reference does
         self.expected_image_size = _ReIDFacade.PRETRAINED_SIZE
@@ -92,13 +92,11 @@ class BUSCA:
         if path is not None and path != "no":
             reid_sd = self._read_checkpoint(path)
             reid_sd = {k: v for k, v in reid_sd.items() if "fc" not in k.split(".") and "fc_person" not in k.split(".")}
-        base = synth.reid_state_dict(seed)
-        if reid_sd is not None:
-            base.update({k: np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v, dtype=np.float32)
-                         for k, v in reid_sd.items() if k in base})
-        for k, v in base.items():
+        for k, v in synth.reid_state_dict(seed).items():
             sd[_REID_PREFIX + k] = v
         self._sd = sd
+        if reid_sd is not None:             # load_net (busca/reid/load_trained_net.py:43-66): update + strict load_state_dict
+            self._load_checked({_REID_PREFIX + k: v for k, v in reid_sd.items()}, what="reid_weights_file %r" % path, scope=_REID_PREFIX)
 
     # ---- nn.Module-like surface -------------------------------------------------------------------------
     @staticmethod
@@ -128,7 +126,14 @@ class BUSCA:
     def state_dict(self):
         return OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in self._sd.items())
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, strict=True):
+        """nn.Module.load_state_dict semantics on this model's key space (every parameter of the reference's BUSCA that
+        the hot path reads; BatchNorm running statistics and the ReID classifier heads are not part of it, see
+        `_ignorable`): unexpected / missing keys raise when `strict`."""
+        unexpected = [k for k in sd if k not in self._sd and not self._ignorable(k)]
+        missing = [k for k in self._sd if k not in sd]
+        if strict and (unexpected or missing):
+            raise RuntimeError("Error(s) in loading state_dict for BUSCA: missing keys {}, unexpected keys {}".format(missing[:8], unexpected[:8]))
         for k, v in sd.items():
             if k in self._sd:
                 arr = np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v, dtype=np.float32)
@@ -136,6 +141,30 @@ class BUSCA:
                     raise RuntimeError("size mismatch for {}: {} vs {}".format(k, arr.shape, self._sd[k].shape))
                 self._sd[k] = np.ascontiguousarray(arr)
         self._dirty = True
+
+    @staticmethod
+    def _ignorable(key):
+        """Keys of a reference checkpoint this implementation has no use for: BatchNorm buffers (train-mode BN at inference
+        never reads running statistics, network.py:553-556), the ReID classifier heads (`plain` output discards them,
+        resnet.py:319-322) and the optimiser-side cls_token."""
+        parts = key.split(".")
+        return (parts[-1] in ("running_mean", "running_var", "num_batches_tracked") or "fc" in parts or "fc_person" in parts
+                or key == "cls_token")
+
+    def _load_checked(self, sd, what, scope="", skip_reid=False):
+        """The reference's `model_dict.update(ckpt); load_state_dict(model_dict)` (network.py:465-467, load_trained_net.py
+        :64-66): keys the model does not have make the strict load RAISE (wrong flavour, DDP `module.` prefix, ...) instead
+        of being dropped; parameters the checkpoint does not supply keep their current value, which is reported."""
+        unexpected = [k for k in sd if k not in self._sd and not self._ignorable(k)]
+        if unexpected:
+            raise RuntimeError("Error(s) in loading state_dict for BUSCA from {}: unexpected key(s) {}{}".format(
+                what, unexpected[:8], " ..." if len(unexpected) > 8 else ""))
+        absent = [k for k in self._sd if k.startswith(scope) and k not in sd and not (skip_reid and k.startswith(_REID_PREFIX))]
+        if absent:
+            import warnings
+            warnings.warn("{}: {} parameter(s) not in the checkpoint keep their current (randomly initialised) values: {}{}".format(
+                what, len(absent), absent[:6], " ..." if len(absent) > 6 else ""))
+        self.load_state_dict({k: v for k, v in sd.items() if k in self._sd}, strict=False)
 
     @property
     def num_params(self):
@@ -158,12 +187,17 @@ class BUSCA:
             sd = {k: v for k, v in sd.items() if "reid_encoder.model." not in k}
         if "cls_token" in sd:
             print("WARNING: Loading a model with a cls_token, but the current model does not have a cls_token. The cls_token will be ignored")
-        self.load_state_dict({k: v for k, v in sd.items() if k in self._sd})
+        if ignore_reid:                     # the ReID keys were dropped on purpose: only the Decision-Transformer part is checked
+            self._load_checked(sd, what="load_pretrained(%r)" % (path,), skip_reid=True)
+            return
+        self._load_checked(sd, what="load_pretrained(%r)" % (path,))
 
     # ---- device state ---------------------------------------------------------------------------------------
     def _sync(self):
         if self._ctx is None:
-            self._ctx = geometry.default_context(self._device_index)
+            # one busca_ctx per model: a context holds ONE Decision-Transformer and ONE ReID weight set, so two BUSCA objects
+            # on one GPU (the reference's modules are independent) must not share one
+            self._ctx = _lib.Context(self._device_index)
         if self._dirty:
             dt_sd = {k: v for k, v in self._sd.items() if not k.startswith(_REID_PREFIX)}
             self._dt = DecisionTransformerHIP(self._ctx, dt_sd, activation=self.effective_activation,
@@ -199,7 +233,7 @@ class BUSCA:
         library).  Small batches are latency-bound, so this nearly halves their ReID time."""
         return self._reid_join(self._reid_side_start(can_u8), self._reid.forward(mem_u8))
 
-    def _reid_side_start(self, u8):
+    def _reid_side_start(self, u8, zero_norm=None):
         """Enqueue one BatchNorm batch on the side stream (ordered after everything already on the current stream)."""
         dev = self._dev()
         cur = torch.cuda.current_stream(dev)
@@ -208,8 +242,10 @@ class BUSCA:
         side = self._side_stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            feat = self._reid.forward(u8, stream=side.cuda_stream)
+            feat = self._reid.forward(u8, stream=side.cuda_stream, zero_norm=zero_norm)
         u8.record_stream(side)
+        if zero_norm is not None:
+            zero_norm.record_stream(side)
         return feat
 
     def _reid_join(self, side_feat, cur_feat):
@@ -263,14 +299,16 @@ class BUSCA:
         H, W = self.expected_image_size
 
         def as_u8(img):
-            if not getattr(img, "host_valid", True):
-                raise RuntimeError("a device-only crop (device_only_crops=True) lost its GPU twin: its host bytes were never copied")
-            img = np.asarray(img)
+            img = np.asarray(img)               # DeviceCrop objects copy their real pixels back here (never placeholders)
             if img.dtype == np.uint8:
                 return img
             # already-normalised float crops (normalize_ims=False callers): map back to the u8 they came from
             v = np.rint((img.astype(np.float64) * tracking._PIXEL_STD + tracking._PIXEL_MEAN) * 255.0)
             return np.clip(v, 0, 255).astype(np.uint8)
+
+        # normalize_ims=False: the caller's crops are already normalised floats and the reference pads with float 0.0 in
+        # NORMALISED space (network.py:285,306,354) - no u8 value maps there, so those crops are flagged for the extractor
+        zero_is_normalised = not normalize_ims
 
         # crops are collected as references; zero crops are None (incomplete memory, padded candidate)
         mem_ref = [[None] * L for _ in range(B)]
@@ -288,7 +326,7 @@ class BUSCA:
 
         # the memory batch does not depend on the proposals: its ReID pass is enqueued NOW (side stream), so the host work
         # below (top-P selection, candidate lists) is hidden behind it
-        mem_feat_side = self._reid_side_start(self._gather_crops(mem_ref, as_u8))
+        mem_feat_side = self._reid_side_start(*self._gather_crops(mem_ref, as_u8, zero_is_normalised))
 
         # top-P nearest detections per track on the GPU (ascending centre distance, ties by lower index)
         order = np.full((B, P), -1, np.int64)
@@ -325,7 +363,8 @@ class BUSCA:
             mem_ltrb[..., 2:] += mem_ltrb[..., :2]
             can_ltrb[..., 2:] += can_ltrb[..., :2]
 
-        can_feat, mem_feat = self._reid_join(mem_feat_side, self._reid.forward(self._gather_crops(can_ref, as_u8)))
+        can_u8, can_zn = self._gather_crops(can_ref, as_u8, zero_is_normalised)
+        can_feat, mem_feat = self._reid_join(mem_feat_side, self._reid.forward(can_u8, zero_norm=can_zn))
         mem_feat, can_feat = mem_feat.view(B, L, -1), can_feat.view(B, P, -1)     # two BN batches
         out = self._dt.forward(mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=self.store_logits)
         self._last = out
@@ -350,24 +389,38 @@ class BUSCA:
             probs_matrix[t, order[t, :n_avail]] = probs[t, :n_avail]
         return probs_matrix, reliable
 
-    def _gather_crops(self, refs, as_u8):
-        """[B][n] crop references (None = all-zero crop) -> cuda u8 [B*n,384,128,3].  Crops that still carry their
-        device twin (tracking.DeviceBackedCrops) are gathered on the GPU; the rest go through one host batch."""
+    def _gather_crops(self, refs, as_u8, zero_is_normalised=False):
+        """[B][n] crop references (None = all-zero crop) -> (cuda u8 [B*n,384,128,3], zero flags | None) with ONE index-gather
+        launch (busca_gather_crops): crops that still own a slot of the device crop pool are read where they are; the rest
+        (plain arrays, spilled slots) go through one host batch first.  Replaces `_get_track_mem` + np.array stacking + H2D
+        of network.py:247-279,313-316,383-386."""
         dev = self._dev()
-        H, W = self.expected_image_size
         flat = [r for row in refs for r in row]
-        out = torch.zeros(len(flat), H, W, 3, dtype=torch.uint8, device=dev)
-        on_dev = [(i, r.dev) for i, r in enumerate(flat)
-                  if r is not None and getattr(r, "dev", None) is not None and r.dev.device == dev]
-        taken = {i for i, _ in on_dev}
-        on_host = [(i, r) for i, r in enumerate(flat) if r is not None and i not in taken]
-        if on_dev:
-            out[torch.tensor([i for i, _ in on_dev], device=dev)] = torch.stack([d for _, d in on_dev])
-        if on_host:
-            host = np.stack([as_u8(r) for _, r in on_host])
-            out[torch.tensor([i for i, _ in on_host], device=dev)] = torch.from_numpy(host).to(dev)
-        self.last_gather = (len(on_dev), len(on_host))       # (device-resident, host) crops of the last call
-        return out
+        ptrs = np.zeros(len(flat), np.uint64)
+        host_idx, host_arr = [], []
+        for i, r in enumerate(flat):
+            if r is None:
+                continue
+            slot = getattr(r, "slot", None)
+            if slot is not None and slot.ptr and slot.pool.device == dev:
+                ptrs[i] = slot.ptr
+            else:
+                host_idx.append(i)
+                host_arr.append(as_u8(r))
+        staged = None
+        if host_idx:
+            staged = torch.from_numpy(np.stack(host_arr)).to(dev)
+            base = staged.data_ptr()
+            for k, i in enumerate(host_idx):
+                ptrs[i] = base + k * (384 * 128 * 3)
+        out = geometry.gather_crops(self._ctx, ptrs)
+        if staged is not None:
+            staged.record_stream(torch.cuda.current_stream(dev))
+        self.last_gather = (len(flat) - len(host_idx) - int((ptrs == 0).sum()), len(host_idx))   # (device-resident, host) crops
+        zn = None
+        if zero_is_normalised and (ptrs == 0).any():
+            zn = torch.from_numpy((ptrs == 0).astype(np.uint8)).to(dev)
+        return out, zn
 
     # ---- helpers with the reference's names ------------------------------------------------------------------
     def _get_track_mem(self, track, seq_len, use_broader_memory):

@@ -1,4 +1,6 @@
 """Host handle of the ReID feature extractor kernels (busca_reid_* in include/busca_hip.h)."""
+import weakref
+
 import numpy as np
 import torch
 
@@ -14,12 +16,25 @@ class ReIDEncoderHIP:
         """precision "f16": fp16 activations/weights (fast); "f32": exact float32 convs (reference-exact, ~6x slower)."""
         self.ctx = ctx
         self.precision = precision
-        blob = weights.reid_blob(state_dict, prefix)
+        self._blob = weights.reid_blob(state_dict, prefix)
         want = ctx.lib.busca_reid_blob_floats()
-        assert blob.size == want, (blob.size, want)
-        ctx.check(ctx.lib.busca_reid_load_weights_ex(ctx.h, blob.ctypes.data, blob.size, {"f16": 1, "f32": 0}[precision]))
+        assert self._blob.size == want, (self._blob.size, want)
+        self._upload()
 
-    def forward(self, crops_u8, stream=None):
+    def _upload(self):
+        ctx = self.ctx
+        ctx.check(ctx.lib.busca_reid_load_weights_ex(ctx.h, self._blob.ctypes.data, self._blob.size, {"f16": 1, "f32": 0}[self.precision]))
+        ctx.reid_owner = weakref.ref(self)
+
+    def _ensure_loaded(self):
+        """A busca_ctx holds ONE ReID weight set; restore this model's if another handle replaced it (see dt.py)."""
+        owner = getattr(self.ctx, "reid_owner", None)
+        if owner is None or owner() is not self:
+            self._upload()
+
+    def forward(self, crops_u8, stream=None, zero_norm=None):
+        """`zero_norm` (cuda u8 [n] or None): crops flagged 1 are 0.0 after normalisation (busca_reid_forward_ex)."""
+        self._ensure_loaded()
         dev = torch.device("cuda", self.ctx.device)
         if not torch.is_tensor(crops_u8):
             crops_u8 = torch.from_numpy(np.ascontiguousarray(crops_u8))
@@ -28,5 +43,6 @@ class ReIDEncoderHIP:
         n = crops_u8.shape[0]
         feats = torch.empty(n, 512, device=dev)
         s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
-        self.ctx.check(self.ctx.lib.busca_reid_forward(self.ctx.h, crops_u8.data_ptr(), n, feats.data_ptr(), s))
+        zn = zero_norm.data_ptr() if zero_norm is not None else None
+        self.ctx.check(self.ctx.lib.busca_reid_forward_ex(self.ctx.h, crops_u8.data_ptr(), n, zn, feats.data_ptr(), s))
         return feats

@@ -104,50 +104,142 @@ def normalize_crops(u8):
 
 
 class DeviceBackedCrops(np.ndarray):
-    """Host uint8 crops that remember their device-resident twin (device-resident track memory).
+    """Host uint8 crops that remember their device-resident twins (device-resident track memory).
 
-    `get_image_crops(..., normalize=False)` returns this ndarray subclass: to the trackers it is an ordinary
-    uint8 array ([N,384,128,3]; `crops[i]` is what they append to `images_mem`), but every view also carries
-    `.dev`, the matching slice of the CUDA tensor the crop kernel wrote.  `associate_embeddings` gathers the
-    `.dev` views on the GPU and skips the per-frame host->device copy of B*(L+P) crops (147 KB each); crops
-    that lost their twin (np.array(...) copies, other sources) silently take the host path.
+    `get_image_crops(..., normalize=False)` returns this ndarray subclass: to the trackers it is an ordinary uint8
+    array ([N,384,128,3] with REAL host bytes; `crops[i]` is what they append to `images_mem`), but `crops[i]` also
+    carries `.slot`, its slot in the bounded device pool (busca_amd/crop_pool.py).  `associate_embeddings` gathers
+    slots on the GPU and skips the per-frame host->device copy of B*(L+P) crops (147 KB each).  Anything that loses
+    the slot (np.array(...) copies, pickling, arithmetic) is still a correct host crop and takes the host path."""
 
-    `host_valid` is False for the placeholders of `get_image_crops(..., device_only=True)`: their host bytes were never
-    copied back (a zero-stride all-zero array), only `.dev` carries pixels."""
-
-    def __new__(cls, host, dev, host_valid=True):
-        obj = np.asarray(host).view(cls)
-        obj.dev = dev
-        obj.host_valid = host_valid
+    def __new__(cls, host, slots):
+        host = np.asarray(host)
+        obj = host.view(cls)
+        obj._slots = slots
+        obj._host = host                    # the plain array: slot.host views must not reference this subclass (no cycles)
+        obj.slot = None
         return obj
 
     def __array_finalize__(self, obj):
-        self.dev = None                     # generic views/copies do not know which device rows they cover
-        self.host_valid = getattr(obj, "host_valid", True)
+        self._slots = None                  # generic views/copies do not know which pool slots they cover
+        self._host = None
+        self.slot = None
 
     def __getitem__(self, key):
-        out = super().__getitem__(key)
-        if isinstance(out, DeviceBackedCrops) and self.dev is not None and self.ndim == 4 and isinstance(key, (int, np.integer)):
-            out.dev = self.dev[int(key)]
-        return out
+        if self._slots is not None and self.ndim == 4 and isinstance(key, (int, np.integer)):
+            # the crop is a view of the PLAIN host array: it keeps the frame's host bytes alive (as the reference's
+            # np.stack'ed crops do) but not this container, so the other crops' pool slots are free to go
+            k = int(key)
+            out = self._host[k].view(DeviceBackedCrops)
+            out.slot = self._slots[k]
+            if out.slot.host is None:
+                out.slot.host = self._host[k]             # a spill of this crop needs no device->host copy
+            return out
+        return super().__getitem__(key)
+
+    def __reduce__(self):                   # pickling / copy.deepcopy: a plain host array (the slot stays with this process)
+        return np.asarray(self).__reduce__()
+
+    @property
+    def dev(self):
+        """cuda u8 view of this crop's slot ([384,128,3]); None for non-crop views and after a spill."""
+        return self.slot.tensor() if self.slot is not None else None
+
+
+class DeviceCrop(np.lib.mixins.NDArrayOperatorsMixin):
+    """One crop of `get_image_crops(..., device_only=True)`: lives in its pool slot only.  Any host read
+    (`np.array(crop)`, arithmetic, `.astype`, pickling) copies the real pixels back first - there are no placeholder
+    bytes that could leak into a BatchNorm batch."""
+    shape, dtype, ndim, size = (384, 128, 3), np.dtype(np.uint8), 3, 384 * 128 * 3
+
+    def __init__(self, slot):
+        self.slot = slot
+
+    @property
+    def dev(self):
+        return self.slot.tensor()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.slot.host_bytes()
+        return a if dtype is None else a.astype(dtype)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        inputs = tuple(np.asarray(x) if isinstance(x, DeviceCrop) else x for x in inputs)
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def astype(self, dtype, **kw):
+        return np.asarray(self).astype(dtype, **kw)
+
+    def copy(self):
+        return np.array(self.slot.host_bytes())
+
+    def __getitem__(self, key):
+        return np.asarray(self)[key]
+
+    def __len__(self):
+        return 384
+
+    def __reduce__(self):
+        return np.asarray(self).__reduce__()
+
+
+class DeviceCrops:
+    """Sequence of DeviceCrop ([N,384,128,3] uint8 to duck-typing callers); `crops[i]` is what a tracker stores."""
+    dtype, ndim = np.dtype(np.uint8), 4
+
+    def __init__(self, slots):
+        self._items = [DeviceCrop(s) for s in slots]
+
+    @property
+    def shape(self):
+        return (len(self._items), 384, 128, 3)
+
+    def __len__(self):
+        return len(self._items)
+
+    def __iter__(self):
+        return iter(self._items)
+
+    def __getitem__(self, key):
+        if isinstance(key, (int, np.integer)):
+            return self._items[int(key)]
+        return np.asarray(self)[key]
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.stack([np.asarray(c) for c in self._items]) if self._items else np.zeros((0, 384, 128, 3), np.uint8)
+        return a if dtype is None else a.astype(dtype)
+
+
+def box_extents(bboxes):
+    """[n,4] x1y1x2y2 -> int32 (floor(x1), floor(y1), ceil(x2), ceil(y2)) on the caller's float64 values, as
+    busca/tracking.py:84-87 does with math.floor / math.ceil (a float32 copy of the box can land on the other side of
+    an integer).  Clamped to +-2^30 so absurd boxes cannot overflow the kernel's int arithmetic."""
+    b = np.nan_to_num(np.asarray(bboxes, dtype=np.float64).reshape(-1, 4), nan=0.0, posinf=2.0 ** 30, neginf=-2.0 ** 30)
+    r = np.empty(b.shape, np.float64)
+    r[:, :2] = np.floor(b[:, :2])
+    r[:, 2:] = np.ceil(b[:, 2:])
+    return np.clip(r, -2.0 ** 30, 2.0 ** 30).astype(np.int32)
 
 
 def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False):
     """All crops of one frame in one launch: u8 BGR [N,384,128,3] (float32 normalised if `normalize`).
-    `device_only` (with normalize=False): skip the device->host copy of the crops (147 KB each, the bulk of this call);
-    the returned array is a zero-stride placeholder whose `crops[i]` still carry `.dev` - for trackers that only hand the
-    crops back to `associate_embeddings`, which is all the reference's adapters do with them."""
-    bboxes = np.asarray(bboxes, dtype=np.float32).reshape(-1, 4)
-    if len(bboxes) == 0:
+    With normalize=False every crop is written into a slot of the device crop pool and the returned crops remember
+    their slot.  `device_only`: skip the device->host copy of the crops (147 KB each, the bulk of this call); the
+    returned `DeviceCrops` copies pixels back only if something on the host actually reads them."""
+    rects = box_extents(bboxes)
+    if len(rects) == 0:
         return np.zeros([0, 128, 384, 3])            # the reference's (transposed) empty shape, network.py:503
     ctx = ctx or geometry.default_context()
-    u8, _ = geometry.crop_gather(ctx, im, bboxes, want_u8=True)
-    if device_only and not normalize:
-        return DeviceBackedCrops(np.broadcast_to(np.zeros(1, np.uint8), tuple(u8.shape)), u8, host_valid=False)
-    crops = u8.cpu().numpy()
     if normalize:
-        return normalize_crops(crops)
-    return DeviceBackedCrops(crops, u8)
+        u8, _ = geometry.crop_gather(ctx, im, rects, want_u8=True)
+        return normalize_crops(u8.cpu().numpy())
+    pool = geometry.crop_pool(ctx)
+    slots = pool.alloc(len(rects))
+    geometry.crop_gather(ctx, im, rects, want_u8=False, dst_ptrs=np.array([s.ptr for s in slots], dtype=np.uint64))
+    if device_only:
+        return DeviceCrops(slots)
+    host = geometry.gather_crops(ctx, np.array([s.ptr for s in slots], dtype=np.uint64)).cpu().numpy()
+    return DeviceBackedCrops(host, slots)
 
 
 def get_bbox_crop(im, bbox_real_scale, output_size=(128, 384), normalize=True, ghost_normalize=True, ctx=None):

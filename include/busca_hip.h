@@ -150,6 +150,23 @@ int busca_duplicate_masks(busca_ctx* ctx, const double* cost, int32_t nA, int32_
 int busca_crop_gather(busca_ctx* ctx, const uint8_t* frame, int32_t H, int32_t W, int32_t stride,
                       const float* boxes, int32_t n, uint8_t* out_u8, void* out_f16, void* stream);
 
+/*
+ * The same with the box extents already rounded by the caller and optional per-crop destinations:
+ *   rects  dev i32 [n,4] = (floor(x1), floor(y1), ceil(x2), ceil(y2)) - busca/tracking.py:84-87 applies math.floor / math.ceil
+ *          to the caller's float64 values (`tlbr * scale`); rounding them on the host in float64 keeps the cut-out extent
+ *          identical where a float32 copy of the box would land on the other side of an integer.
+ *   dst_u8 dev u64 [n] or NULL: when given, crop i (147 456 bytes, u8 BGR) is written to address dst_u8[i] (a slot of the
+ *          device-resident crop pool, busca_amd/crop_pool.py) instead of out_u8 + i*147456; out_u8 may then be NULL.
+ */
+int busca_crop_gather_ex(busca_ctx* ctx, const uint8_t* frame, int32_t H, int32_t W, int32_t stride, const int32_t* rects,
+                         int32_t n, const uint64_t* dst_u8, uint8_t* out_u8, void* out_f16, void* stream);
+/*
+ * Index gather of track memories (busca/network.py:247-279 `_get_track_mem` + the np.array(...) stacking of :313,383):
+ * out dev u8 [n,384,128,3]; crop i is copied from device address src[i] (dev u64 [n]); src[i] == 0 gives an all-zero crop
+ * (incomplete memory :306, padded candidate :354).
+ */
+int busca_gather_crops(busca_ctx* ctx, const uint64_t* src, int32_t n, uint8_t* out, void* stream);
+
 /* ---- ReID feature extractor (busca/network.py:510-575 + busca/reid/resnet.py:266-322) --------- */
 /* Number of float32 values in the ReID weight blob (layout: see busca_amd/weights.py:reid_blob). */
 size_t busca_reid_blob_floats(void);
@@ -160,6 +177,10 @@ int busca_reid_load_weights_ex(busca_ctx* ctx, const float* blob, size_t blob_fl
 /* crops: dev u8 [n,384,128,3] BGR (what the trackers keep in images_mem).  feats: dev f32 [n,512],
  * L2-normalised.  ONE CALL == ONE BatchNorm batch (train-mode statistics, network.py:553-556). */
 int busca_reid_forward(busca_ctx* ctx, const uint8_t* crops, int32_t n, float* feats, void* stream);
+/* zero_norm dev u8 [n] or NULL: 1 marks a crop whose pixels are 0.0 AFTER normalisation - the zero crops of
+ * associate_embeddings(normalize_ims=False) (busca/network.py:285,306,354: float32 zeros that skip _normalize_embeddings_batch);
+ * its bytes in `crops` are ignored.  With normalize_ims=True the zero crops are u8 zeros and need no flag. */
+int busca_reid_forward_ex(busca_ctx* ctx, const uint8_t* crops, int32_t n, const uint8_t* zero_norm, float* feats, void* stream);
 /* Bytes of device workspace busca_reid_forward needs for n crops (allocated lazily inside the ctx). */
 size_t busca_reid_workspace_bytes(int32_t n);
 /*

@@ -18,11 +18,14 @@ def get_track_mem_indices(n_hist, seq_len, use_broader_memory):
     return list(range(n_hist))[-seq_len:]
 
 
-def build_batch(tracks, dets, dists, seq_len, num_candidates, use_broader_memory, kalman=(), pinned_numpy=True):
+def build_batch(tracks, dets, dists, seq_len, num_candidates, use_broader_memory, kalman=(), pinned_numpy=True, normalize_ims=True):
     """network.py:293-398 up to the forward call.  Returns dict with u8 crops, float32 ltrb boxes,
-    candidate global indices (None for padding), n_avail and the reliable flags."""
+    candidate global indices (None for padding), n_avail and the reliable flags.
+    normalize_ims=False (network.py:285): the crops are float32, already normalised by the caller, and the zero crops of
+    incomplete memories / padded candidates are float 0.0 in that normalised space; `mem_u8` / `can_u8` are then float32."""
     B = len(tracks)
-    mem_u8 = np.zeros((B, seq_len, IMG_H, IMG_W, 3), np.uint8)
+    im_dtype = np.uint8 if normalize_ims else np.float32
+    mem_u8 = np.zeros((B, seq_len, IMG_H, IMG_W, 3), im_dtype)
     mem_box = np.zeros((B, seq_len, 4), np.float64)
     reliable = np.zeros(B, bool)
     for t, trk in enumerate(tracks):
@@ -35,7 +38,7 @@ def build_batch(tracks, dets, dists, seq_len, num_candidates, use_broader_memory
         else:                                                        # :303-308
             mem_box[t] = np.array([250.0, 250.0, 500.0, 500.0])
     P = num_candidates
-    can_u8 = np.zeros((B, P, IMG_H, IMG_W, 3), np.uint8)
+    can_u8 = np.zeros((B, P, IMG_H, IMG_W, 3), im_dtype)
     can_box = np.zeros((B, P, 4), np.float64)
     inds = []
     n_avail = min(len(dets), P)
@@ -87,14 +90,14 @@ def scatter_probs(probs, inds, n_avail, n_tracks, n_dets, n_kalman, select_highe
 
 def associate_embeddings(step_fn, tracks, dets, dists, seq_len, num_candidates, use_broader_memory,
                          select_highest_candidate, highest_candidate_minimum_thresh=None,
-                         keep_highest_value=False, extra_kalman_candidates=(), pinned_numpy=True):
+                         keep_highest_value=False, extra_kalman_candidates=(), pinned_numpy=True, normalize_ims=True):
     """network.py:282-429."""
     if len(tracks) == 0:
         return None, None
     if len(dets) == 0 and len(extra_kalman_candidates) == 0:
         return None, None
     b = build_batch(tracks, dets, dists, seq_len, num_candidates, use_broader_memory,
-                    extra_kalman_candidates, pinned_numpy)
+                    extra_kalman_candidates, pinned_numpy, normalize_ims)
     probs = step_fn(b["mem_u8"], b["can_u8"], b["mem_ltrb"], b["can_ltrb"])
     out = scatter_probs(probs, b["inds"], b["n_avail"], len(tracks), len(dets), len(extra_kalman_candidates),
                         select_highest_candidate, highest_candidate_minimum_thresh, keep_highest_value)

@@ -385,6 +385,49 @@ def make_assoc_select(ref):
     print("wrote assoc_select", {k: v.shape for k, v in out.items()})
 
 
+def normalise(images):
+    """network.py:470-478 applied to a list of u8 crops -> list of float32 crops (what a normalize_ims=False caller holds)."""
+    out = []
+    for im in images:
+        x = np.asarray(im).astype(np.float32) / 255.0
+        x -= np.array([0.406, 0.456, 0.485])
+        x /= np.array([0.225, 0.224, 0.299])
+        out.append(x)
+    return out
+
+
+def denormalise(images):
+    return [np.clip(np.rint((np.asarray(x).astype(np.float64) * np.array([0.225, 0.224, 0.299]) + np.array([0.406, 0.456, 0.485])) * 255.0), 0, 255).astype(np.uint8)
+            for x in images]
+
+
+def assoc_nonorm_scene():
+    """Scene for normalize_ims=False: float32 pre-normalised crops, one incomplete memory (float zero crops), fewer
+    detections than candidates (float zero padding)."""
+    tracks, dets, kals = assoc_scene(31, [14, 4, 11], 2, True)
+    f32 = lambda trk: FakeTrack(trk.tlwh_mem, normalise(trk.images_mem), trk.scale)
+    return [f32(t) for t in tracks], [f32(t) for t in dets], [f32(t) for t in kals]
+
+
+def make_assoc_nonorm(ref):
+    ref_network, ref_tracking, _ = ref
+    d, ff, seed = 64, 128, 17
+    model = build_ref_model(ref_network, d, ff)
+    load_dt_weights(model, synth.dt_state_dict(seed, d=d, ff=ff))
+    model.reid_encoder = ref_network.ReID_Encoder(num_classes=299, device=torch.device("cpu"), pretrained_path="no",
+                                                  use_domain_adaptation=True, trainable=False, use_checkpointing=False)
+    load_reid_weights(model.reid_encoder, seed)
+    set_fake_dtype(model, True)
+    tracks, dets, kals = assoc_nonorm_scene()
+    dists = ref_tracking.center_distance(np.array([t.tlbr * t.scale for t in tracks]), np.array([x.tlbr * x.scale for x in dets]))
+    with torch.no_grad():
+        pm, rel = model.associate_embeddings(tracks_embeddings=tracks, dets_embeddings=dets, dists_matrix=dists, seq_len=11, num_candidates=5,
+                                             use_broader_memory=True, select_highest_candidate=False, extra_kalman_candidates=kals,
+                                             normalize_ims=False)
+    np.savez_compressed(os.path.join(OUT, "assoc_nonorm.npz"), probs=pm, reliable=rel, dists=dists)
+    print("wrote assoc_nonorm", pm.shape, rel)
+
+
 ASSOC512_CASE = ("r", [15, 3, 11, 12, 40, 11], 9, True, 5)
 
 
@@ -454,7 +497,7 @@ def main():
     if "assoc512" in which:
         make_assoc512(ref)
         _MODELS.pop((512, 1024), None)
-    for name in ("enc", "enc_big", "geom", "assoc", "assoc_select", "reid", "reid_big", "track"):
+    for name in ("enc", "enc_big", "geom", "assoc", "assoc_select", "assoc_nonorm", "reid", "reid_big", "track"):
         fn = globals().get("make_" + name)
         if name in which and fn is not None:
             fn(ref)

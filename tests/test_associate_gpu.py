@@ -108,8 +108,9 @@ def test_device_resident_track_memory(model):
     frame = synth.randint_u8(4, "frame", (540, 960, 3))
     boxes = np.array([[50 + 30 * i, 40 + 5 * i, 110 + 30 * i, 260 + 5 * i] for i in range(24)], np.float32)
     crops = model.get_image_crops(frame, boxes, normalize=False)
-    assert isinstance(crops, DeviceBackedCrops) and crops.dev is not None and crops[3].dev is not None
+    assert isinstance(crops, DeviceBackedCrops) and crops[3].slot is not None and crops[3].dev is not None
     assert np.array_equal(crops[3].dev.cpu().numpy(), np.asarray(crops[3]))
+    assert type(np.array(crops[3])) is np.ndarray and getattr(np.array(crops[3]), "slot", None) is None
     hist = [mg.FakeTrack([[50, 40, 60, 220]] * 12, [crops[i] for i in range(12)]), mg.FakeTrack([[300, 80, 60, 220]] * 11, [crops[i] for i in range(12, 23)])]
     dets = [mg.FakeTrack([[55, 45, 60, 220]], [crops[23]]), mg.FakeTrack([[310, 85, 60, 220]], [crops[5]])]
     kal = [mg.FakeTrack([[52, 42, 60, 220]], [crops[1]]), mg.FakeTrack([[305, 82, 60, 220]], [crops[14]])]
@@ -147,9 +148,12 @@ def test_associate_exact_flavours_vs_reference(golden_dir, ci):
 
 
 def test_device_only_crops(model):
-    """device_only_crops: get_image_crops skips the device->host copy; the placeholders still associate through their GPU
-    twins (bit-identical), and a placeholder that lost its twin is refused instead of silently contributing zeros."""
+    """device_only_crops: get_image_crops skips the device->host copy; the crops associate through their pool slots
+    (bit-identical), and ANY host read of such a crop (np.array, arithmetic, astype, pickle) returns the real pixels -
+    there are no placeholder bytes that could reach a BatchNorm batch."""
+    import pickle
     import make_golden as mg
+    from busca_amd.tracking import DeviceCrops
     model.pinned_numpy = True
     model._dirty = True
     frame = synth.randint_u8(4, "frame", (540, 960, 3))
@@ -161,21 +165,128 @@ def test_device_only_crops(model):
         kal = [mg.FakeTrack([[52, 42, 60, 220]], [crops[1]]), mg.FakeTrack([[305, 82, 60, 220]], [crops[14]])]
         return hist, dets, kal
     dists = np.array([[7.0, 250.0], [250.0, 11.0]])
-    h, d, k = scene(model.get_image_crops(frame, boxes, normalize=False))
+    ref_crops = model.get_image_crops(frame, boxes, normalize=False)
+    h, d, k = scene(ref_crops)
     a, ra = model.associate_embeddings(h, d, dists, 11, 5, True, False, extra_kalman_candidates=k, normalize_ims=True)
     model.device_only_crops = True
     try:
         crops = model.get_image_crops(frame, boxes, normalize=False)
-        assert crops.shape == (24, 384, 128, 3) and crops.strides == (0, 0, 0, 0) and not crops[2].host_valid and crops[2].dev is not None
+        assert isinstance(crops, DeviceCrops) and crops.shape == (24, 384, 128, 3) and len(crops) == 24 and crops[2].dev is not None
+        assert crops[2].slot.host is None                                     # nothing was copied back
         h, d, k = scene(crops)
         b, rb = model.associate_embeddings(h, d, dists, 11, 5, True, False, extra_kalman_candidates=k, normalize_ims=True)
         assert model.last_gather[1] == 0
         assert np.array_equal(a, b) and np.array_equal(ra, rb)
-        d[0].images_mem = [np.array(d[0].images_mem[0], subok=True)]          # a copy: twin gone, bytes never existed
-        with pytest.raises(RuntimeError, match="device-only crop"):
-            model.associate_embeddings(h, d, dists, 11, 5, True, False, extra_kalman_candidates=k, normalize_ims=True)
+        # host reads give the real pixels, whatever the route
+        truth = np.asarray(ref_crops[7])
+        assert np.array_equal(np.array(crops[7]), truth) and type(np.array(crops[7])) is np.ndarray
+        assert np.array_equal(np.ascontiguousarray(crops[8]), np.asarray(ref_crops[8]))
+        assert np.array_equal(np.stack([crops[9], crops[10]]), np.asarray(ref_crops[9:11]))
+        assert np.array_equal(crops[11].astype(np.float32), np.asarray(ref_crops[11]).astype(np.float32))
+        assert np.allclose(crops[12] / 255.0, np.asarray(ref_crops[12]) / 255.0)
+        assert np.array_equal(pickle.loads(pickle.dumps(crops[13])), np.asarray(ref_crops[13]))
+        assert np.array_equal(np.asarray(crops)[3], np.asarray(ref_crops[3]))
+        # a copy has no slot: it takes the host path with the same pixels -> same result
+        d[0].images_mem = [np.array(d[0].images_mem[0])]
+        c2, _ = model.associate_embeddings(h, d, dists, 11, 5, True, False, extra_kalman_candidates=k, normalize_ims=True)
+        assert model.last_gather[1] == 1 and np.array_equal(c2, a)
     finally:
         model.device_only_crops = False
+
+
+def test_two_models_on_one_gpu_do_not_share_weights():
+    """Two BUSCA objects (different shapes and weights) used alternately give what each gives alone; the same for two
+    DecisionTransformerHIP / ReIDEncoderHIP handles that share one context."""
+    import make_golden as mg
+    from busca_amd import _lib
+    from busca_amd.dt import DecisionTransformerHIP
+    from busca_amd.reid import ReIDEncoderHIP
+    m1, m2 = _model(64, 128, 17), _model(256, 512, 5)
+    name, tracks, dets, kals, P = _case(0)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "assoc.npz"))
+    dists = g[name + "_dists"]
+    run = lambda m: m.associate_embeddings(tracks, dets, dists, 11, P, True, False, extra_kalman_candidates=kals, normalize_ims=True)[0]
+    a1 = run(m1); a2 = run(m2); b1 = run(m1); b2 = run(m2)
+    assert np.array_equal(a1, b1) and np.array_equal(a2, b2) and not np.array_equal(a1, a2)
+    assert m1._ctx is not m2._ctx
+    ctx = _lib.Context(0)
+    inp = synth.dt_inputs(3, 4, 11, 5)
+    f = lambda m: m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])["logits"].cpu().numpy()
+    d1 = DecisionTransformerHIP(ctx, synth.dt_state_dict(1, d=64, ff=128), precision="f32")
+    x1 = f(d1)
+    d2 = DecisionTransformerHIP(ctx, synth.dt_state_dict(2, d=256, ff=512), precision="f16")
+    x2 = f(d2)
+    assert np.array_equal(f(d1), x1) and np.array_equal(f(d2), x2) and np.array_equal(f(d1), x1)
+    crops = mg.smooth_crops(9, 4)
+    r1 = ReIDEncoderHIP(ctx, synth.reid_state_dict(1)); y1 = r1.forward(crops).cpu().numpy()
+    r2 = ReIDEncoderHIP(ctx, synth.reid_state_dict(2), precision="f32"); y2 = r2.forward(crops).cpu().numpy()
+    assert np.array_equal(r1.forward(crops).cpu().numpy(), y1) and np.array_equal(r2.forward(crops).cpu().numpy(), y2)
+    ctx.close()
+
+
+def test_crop_pool_is_bounded_over_a_long_sequence(model):
+    """2 000 simulated frames: tracks are born, grow their `images_mem`, die.  HBM held by the crop pool stays flat
+    (slots return when the last reference to a crop dies; beyond the budget the oldest crops spill to the host), and an
+    association that mixes resident and spilled crops equals the all-host path bit for bit."""
+    import make_golden as mg
+    from busca_amd import geometry
+    from busca_amd.crop_pool import CropPool, CROP_BYTES
+    model.pinned_numpy = True
+    model._dirty = True
+    model._sync()
+    ctx = model._ctx
+    ctx._crop_pool = CropPool(ctx.device, budget_bytes=1024 * CROP_BYTES, slab_crops=256)       # small budget: 1 024 crops
+    pool = geometry.crop_pool(ctx)
+    frame = synth.randint_u8(4, "frame", (540, 960, 3))
+    rng = np.random.default_rng(0)
+    tracks, sizes = [], []
+    torch.cuda.synchronize()
+    for f in range(2000):
+        n = 12
+        x = rng.uniform(0, 800, n); y = rng.uniform(0, 300, n)
+        boxes = np.stack([x, y, x + rng.uniform(30, 120, n), y + rng.uniform(80, 220, n)], 1)
+        crops = model.get_image_crops(frame, boxes, normalize=False)
+        if f % 7 == 0 or not tracks:
+            tracks.append(mg.FakeTrack([boxes[0][:2].tolist() + [60, 200]], [crops[0]]))
+        for t_i, trk in enumerate(tracks[:n - 1]):
+            trk.images_mem.append(crops[1 + t_i])
+            trk.tlwh_mem.append(trk.tlwh_mem[-1])
+        if len(tracks) > 8:                                  # the oldest track dies: its crops leave the pool
+            tracks.pop(0)
+        sizes.append(pool.device_bytes)
+    assert max(sizes) <= 1024 * CROP_BYTES and sizes[-1] == sizes[len(sizes) // 2]       # flat
+    assert pool.n_live <= 1024
+    assert pool.spilled > 0                                  # the budget was exceeded and handled
+    long_tracks = [t for t in tracks if len(t.images_mem) >= 11]
+    assert long_tracks
+    dets = [mg.FakeTrack([[55, 45, 60, 220]], [long_tracks[0].images_mem[-1]])]
+    dists = np.zeros((len(long_tracks), 1))
+    a, ra = model.associate_embeddings(long_tracks, dets, dists, 11, 5, True, False, extra_kalman_candidates=long_tracks, normalize_ims=True)
+    mixed = model.last_gather
+    plain = lambda trk: mg.FakeTrack(trk.tlwh_mem, [np.array(c) for c in trk.images_mem], trk.scale)
+    pl = [plain(t) for t in long_tracks]
+    b, rb = model.associate_embeddings(pl, [plain(dets[0])], dists, 11, 5, True, False, extra_kalman_candidates=pl, normalize_ims=True)
+    assert model.last_gather[0] == 0 and mixed[0] > 0
+    assert np.array_equal(a, b) and np.array_equal(ra, rb)
+    ctx._crop_pool = None
+
+
+def test_associate_prenormalised_inputs_vs_reference(golden_dir):
+    """normalize_ims=False (the function's default; no shipped adapter uses it): the caller's crops are already normalised
+    float32 and the reference's zero crops are 0.0 AFTER normalisation (network.py:285,306,354)."""
+    import make_golden as mg
+    m = _model(64, 128, 17, "f32", "f32")
+    g = np.load(os.path.join(golden_dir, "assoc_nonorm.npz"))
+    tracks, dets, kals = mg.assoc_nonorm_scene()
+    pm, rel = m.associate_embeddings(tracks, dets, g["dists"], 11, 5, True, False, extra_kalman_candidates=kals, normalize_ims=False)
+    assert np.array_equal(rel, g["reliable"])
+    assert np.array_equal(pm == 0, g["probs"] == 0)
+    assert np.abs(pm - g["probs"]).max() <= 2e-4, np.abs(pm - g["probs"]).max()
+    # and the u8 route with the reference's u8-zero padding differs (the zero crops sit elsewhere in the BN batch)
+    u8 = lambda trk: mg.FakeTrack(trk.tlwh_mem, mg.denormalise(trk.images_mem), trk.scale)
+    pm2, _ = m.associate_embeddings([u8(t) for t in tracks], [u8(t) for t in dets], g["dists"], 11, 5, True, False,
+                                    extra_kalman_candidates=[u8(t) for t in kals], normalize_ims=True)
+    assert np.abs(pm2 - g["probs"]).max() > 1e-3
 
 
 def _model(d, ff, seed, precision="f32", reid_precision="f16"):

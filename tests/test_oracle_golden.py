@@ -260,3 +260,28 @@ def test_associate_shipped_shape_matches_reference(golden_dir):
     pm, rel = oa.associate_embeddings(_oracle_step(23, 512, 1024), tracks, dets, g[name + "_dists"], 11, P, True, False, extra_kalman_candidates=kals)
     assert np.array_equal(rel, g[name + "_reliable"])
     np.testing.assert_allclose(pm, g[name + "_probs_f64_sel0"], rtol=0, atol=5e-5)
+
+
+def test_associate_prenormalised_inputs_match_reference(golden_dir):
+    """normalize_ims=False: float32 pre-normalised crops, zero padding in normalised space (network.py:285,306,354)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    from oracle import associate as oa, reid as oreid
+    g = np.load(os.path.join(golden_dir, "assoc_nonorm.npz"))
+    tracks, dets, kals = mg.assoc_nonorm_scene()
+    sd_dt, sd_reid = synth.dt_state_dict(17, d=64, ff=128), synth.reid_state_dict(17)
+    cfg = odt.DTConfig(d=64, ff=128, fake_f64=True)
+
+    def step(mem_f, can_f, mem_ltrb, can_ltrb):
+        B, L = mem_f.shape[:2]
+        P_ = can_f.shape[1]
+        chw = lambda x: torch.from_numpy(x).float()[..., [2, 1, 0]].permute(0, 3, 1, 2)      # network.py:397,188
+        mf = oreid.reid_forward(sd_reid, chw(mem_f.reshape(B * L, 384, 128, 3))).view(B, L, -1)
+        cf = oreid.reid_forward(sd_reid, chw(can_f.reshape(B * P_, 384, 128, 3))).view(B, P_, -1)
+        return torch.softmax(odt.dt_forward(sd_dt, cfg, mf, cf, mem_ltrb, can_ltrb), -1).numpy()
+
+    pm, rel = oa.associate_embeddings(step, tracks, dets, g["dists"], 11, 5, True, False, extra_kalman_candidates=kals, normalize_ims=False)
+    assert np.array_equal(rel, g["reliable"])
+    np.testing.assert_allclose(pm, g["probs"], rtol=0, atol=5e-5)

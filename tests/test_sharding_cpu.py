@@ -20,6 +20,54 @@ def test_assign_sequences_lpt():
     assert sharding.assign_sequences(frames, 2) == b               # deterministic
 
 
+def test_split_tracks_partitions_a_step():
+    """SURVEY.md 8e case 2: B tracks of one step over N ranks - contiguous, disjoint, complete, balanced to one track."""
+    import numpy as np
+    for B, N in ((512, 8), (512, 3), (5, 8), (0, 2), (31, 2)):
+        parts = sharding.split_tracks(B, N)
+        assert len(parts) == N and parts[0][0] == 0 and parts[-1][1] == B
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(N - 1))
+        sizes = [hi - lo for lo, hi in parts]
+        assert max(sizes) - min(sizes) <= 1 and sharding.split_tracks(B, N, rank=N - 1) == parts[-1]
+    full = np.arange(31 * 7, dtype=np.float32).reshape(31, 7)
+    assert np.array_equal(sharding.concat_tracks([full[lo:hi] for lo, hi in sharding.split_tracks(31, 4)]), full)
+    assert np.array_equal(sharding.concat_tracks([full[lo:hi] for lo, hi in sharding.split_tracks(31, 40)]), full)   # empty slices
+
+
+def _split_worker(rank, world, port, q):
+    """Each rank computes a (stand-in) per-track function on ITS slice of the step only; the gathered result must equal
+    the single-process result - tracks are independent, no data-path collective."""
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, P = 37, 5
+    feats = np.random.default_rng(5).standard_normal((B, 11 + P, 8)).astype(np.float32)       # same on every rank (seeded)
+    per_track = lambda x: np.tanh(x.sum(axis=1))[:, :P + 2]                                     # any per-track function
+    lo, hi = sharding.split_tracks(B, world, rank)
+    mine = per_track(feats[lo:hi])
+    full = sharding.gather_track_slices(mine, dist)
+    q.put((rank, (lo, hi), bool(np.array_equal(full, per_track(feats))), full.shape))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_track_split_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == (0, 19) and res[1][1] == (19, 37)
+    assert all(r[2] for r in res) and res[0][3] == (37, 7)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
