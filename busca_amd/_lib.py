@@ -27,6 +27,7 @@ SIGNATURES = {
     "busca_dt_blob_floats": (_sz, [C.POINTER(DTCfg)]),
     "busca_dt_load_weights": (C.c_int, [_vp, C.POINTER(DTCfg), _vp, _sz, _vp, _vp, _vp, _i32]),
     "busca_dt_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "busca_dt_reserve": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "busca_dt_bucket_ids": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "busca_timing_enable": (C.c_int, [_vp, _i32]),
     "busca_timing_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), _i32]),

@@ -26,9 +26,9 @@
 #include "dt_tiled.hip.inc"
 
 // ---------------------------------------------------------------------------------------------------------
-struct DTTiledW {                   // row-major f16 copies of the matrices for the tiled path (f16 precision only)
-    const _Float16* w_embed = nullptr;
-    const _Float16 *w_in[DT_MAX_LAYERS] = {}, *w_out[DT_MAX_LAYERS] = {}, *w1[DT_MAX_LAYERS] = {}, *w2[DT_MAX_LAYERS] = {};
+struct DTTiledW {                   // row-major copies of the matrices for the tiled path, in the operand type (f16 or f32)
+    const void* w_embed = nullptr;
+    const void *w_in[DT_MAX_LAYERS] = {}, *w_out[DT_MAX_LAYERS] = {}, *w1[DT_MAX_LAYERS] = {}, *w2[DT_MAX_LAYERS] = {};
 };
 
 struct DTState {
@@ -273,21 +273,28 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
     S.cfg = *g;
     if (S.dev_tiled) { HIP_TRY(c, hipFree(S.dev_tiled)); S.dev_tiled = nullptr; }
     S.tw = DTTiledW();
-    if (prec == BUSCA_PREC_F16) {   // plain row-major f16 matrices for the tiled (layer-wise) path
-        std::vector<_Float16> hw;
-        auto put16 = [&](const float* src, size_t n) { while (hw.size() % 8) hw.push_back((_Float16)0.f); size_t off = hw.size(); for (size_t i = 0; i < n; ++i) hw.push_back((_Float16)src[i]); return off; };
+    {   // plain row-major matrices in the operand type for the tiled (layer-wise) path
+        std::vector<unsigned char> hw;
+        auto putm = [&](const float* src, size_t n) {
+            while (hw.size() % 16) hw.push_back(0);
+            const size_t off = hw.size();
+            hw.resize(off + n * es);
+            if (prec == BUSCA_PREC_F32) memcpy(hw.data() + off, src, n * 4);
+            else { _Float16* d16 = (_Float16*)(hw.data() + off); for (size_t i = 0; i < n; ++i) d16[i] = (_Float16)src[i]; }
+            return off;
+        };
         const float* q = blob;
-        const size_t o_e = put16(q, (size_t)d * E); q += (size_t)d * E + d + 3 * d;
+        const size_t o_e = putm(q, (size_t)d * E); q += (size_t)d * E + d + 3 * d;
         size_t oi[DT_MAX_LAYERS], oo[DT_MAX_LAYERS], o1[DT_MAX_LAYERS], o2[DT_MAX_LAYERS];
         for (int l = 0; l < g->nlayers; ++l) {
-            oi[l] = put16(q, (size_t)3 * d * d); q += (size_t)3 * d * d + 3 * d;
-            oo[l] = put16(q, (size_t)d * d); q += (size_t)d * d + d;
-            o1[l] = put16(q, (size_t)ff * d); q += (size_t)ff * d + ff;
-            o2[l] = put16(q, (size_t)d * ff); q += (size_t)d * ff + d + 4 * d;
+            oi[l] = putm(q, (size_t)3 * d * d); q += (size_t)3 * d * d + 3 * d;
+            oo[l] = putm(q, (size_t)d * d); q += (size_t)d * d + d;
+            o1[l] = putm(q, (size_t)ff * d); q += (size_t)ff * d + ff;
+            o2[l] = putm(q, (size_t)d * ff); q += (size_t)d * ff + d + 4 * d;
         }
-        HIP_TRY(c, hipMalloc(&S.dev_tiled, hw.size() * sizeof(_Float16)));
-        HIP_TRY(c, hipMemcpy(S.dev_tiled, hw.data(), hw.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-        const _Float16* tb = (const _Float16*)S.dev_tiled;
+        HIP_TRY(c, hipMalloc(&S.dev_tiled, hw.size()));
+        HIP_TRY(c, hipMemcpy(S.dev_tiled, hw.data(), hw.size(), hipMemcpyHostToDevice));
+        const char* tb = (const char*)S.dev_tiled;
         S.tw.w_embed = tb + o_e;
         for (int l = 0; l < g->nlayers; ++l) { S.tw.w_in[l] = tb + oi[l]; S.tw.w_out[l] = tb + oo[l]; S.tw.w1[l] = tb + o1[l]; S.tw.w2[l] = tb + o2[l]; }
     }
@@ -332,65 +339,79 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
 }
 
 // ---- tiled (layer-wise) path ---------------------------------------------------------------------------------------
-template <int D, int EPI>
+template <int PREC, int D, int EPI>
 static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblocks) {
     const size_t lds = (size_t)(DTL_BM + D) * 128 + 2 * 4 * DTL_BM * sizeof(float);
-    auto kern = dtl_gemm_kernel<D, EPI>;
+    auto kern = dtl_gemm_kernel<PREC, D, EPI>;
     { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
     TimedLaunch tl(c, s);
     hipLaunchKernelGGL(kern, dim3((a.M + DTL_BM - 1) / DTL_BM, ncolblocks), dim3(512), lds, s, a);
     return BUSCA_OK;
 }
 
-template <int D, int MT>
-static int dtl_attention(busca_ctx* c, hipStream_t s, const _Float16* qkv, _Float16* O, int B, int T, float* att) {
-    constexpr int HD = D / 4, NCK = (MT + 1) / 2;
-    const size_t lds = (size_t)16 * MT * (HD * 2 + 16) + (size_t)HD * (32 * NCK * 2 + 16);
-    auto kern = dtl_attention_kernel<D, MT>;
+template <int PREC, int D, int MT>
+static int dtl_attention(busca_ctx* c, hipStream_t s, const void* qkv, void* O, int B, int T, float* att) {
+    constexpr int ES = Prec<PREC>::ES, HD = D / 4, TPK = Prec<PREC>::CHUNK * Prec<PREC>::nchunks(MT);
+    const size_t lds = (size_t)16 * MT * (HD * ES + 16) + (size_t)HD * (TPK * ES + 16);
+    if (lds > 160 * 1024) return fail(c, BUSCA_EINVAL, "tiled attention: %d tokens x head dim %d do not fit the LDS in this precision", T, HD);
+    auto kern = dtl_attention_kernel<PREC, D, MT>;
     { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
     TimedLaunch tl(c, s);
     hipLaunchKernelGGL(kern, dim3(B, 4), dim3(256), lds, s, qkv, O, T, att);
     return BUSCA_OK;
 }
 
-template <int D>
-static int dtl_attention_mt(busca_ctx* c, hipStream_t s, int MT, const _Float16* qkv, _Float16* O, int B, int T, float* att) {
+template <int PREC, int D>
+static int dtl_attention_mt(busca_ctx* c, hipStream_t s, int MT, const void* qkv, void* O, int B, int T, float* att) {
     switch (MT) {
-        case 1: return dtl_attention<D, 1>(c, s, qkv, O, B, T, att);
-        case 2: return dtl_attention<D, 2>(c, s, qkv, O, B, T, att);
-        case 3: return dtl_attention<D, 3>(c, s, qkv, O, B, T, att);
-        case 4: return dtl_attention<D, 4>(c, s, qkv, O, B, T, att);
-        case 5: return dtl_attention<D, 5>(c, s, qkv, O, B, T, att);
-        case 6: return dtl_attention<D, 6>(c, s, qkv, O, B, T, att);
-        case 7: return dtl_attention<D, 7>(c, s, qkv, O, B, T, att);
-        case 8: return dtl_attention<D, 8>(c, s, qkv, O, B, T, att);
-        case 9: return dtl_attention<D, 9>(c, s, qkv, O, B, T, att);
+        case 1: return dtl_attention<PREC, D, 1>(c, s, qkv, O, B, T, att);
+        case 2: return dtl_attention<PREC, D, 2>(c, s, qkv, O, B, T, att);
+        case 3: return dtl_attention<PREC, D, 3>(c, s, qkv, O, B, T, att);
+        case 4: return dtl_attention<PREC, D, 4>(c, s, qkv, O, B, T, att);
+        case 5: return dtl_attention<PREC, D, 5>(c, s, qkv, O, B, T, att);
+        case 6: return dtl_attention<PREC, D, 6>(c, s, qkv, O, B, T, att);
+        case 7: return dtl_attention<PREC, D, 7>(c, s, qkv, O, B, T, att);
+        case 8: return dtl_attention<PREC, D, 8>(c, s, qkv, O, B, T, att);
+        case 9: return dtl_attention<PREC, D, 9>(c, s, qkv, O, B, T, att);
     }
     return fail(c, BUSCA_EINVAL, "tiled attention supports at most 144 tokens per track (got %d)", T);
 }
 
-template <int D>
+// Workspace of the layer-wise path for M rows (bytes).  Grown outside the forward by busca_dt_reserve; a forward that finds
+// it too small grows it itself (one stream synchronisation + hipMalloc, first call of a larger shape only).
+static size_t dtl_ws_bytes(size_t M, int D, size_t es) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return al(M * D * 4) + al(M * D * 2) + al(M * 3 * D * es) + al(M * D * es) + al(M * 2 * D * es) + al(M * 3 * 4);
+}
+
+static int dtl_ws_ensure(busca_ctx* c, size_t need, hipStream_t s) {
+    DTState& S = c->dt;
+    if (S.ws_bytes >= need) return BUSCA_OK;
+    if (S.ws) { HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(S.ws)); S.ws = nullptr; S.ws_bytes = 0; }
+    if (hipMalloc(&S.ws, need) != hipSuccess) return fail(c, BUSCA_ENOMEM, "cannot allocate %zu bytes of DT workspace", need);
+    S.ws_bytes = need;
+    return BUSCA_OK;
+}
+
+template <int PREC, int D>
 static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     DTState& S = c->dt;
+    constexpr size_t ES = Prec<PREC>::ES;
     const int T = K.T, B = K.B, L = K.L, P = K.P, FF = 2 * D, E = 512;
     const int MT = (T + 15) / 16;
     if (MT > 9) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most 144 tokens per track (T=%d)", T);
     if (P + 2 > 128) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most 126 proposals (P=%d)", P);
     const size_t M = (size_t)B * T;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t need = al(M * D * 4) + al(M * D * 2) + al(M * 3 * D * 2) + al(M * D * 2) + al(M * FF * 2) + al(M * 3 * 4);
-    if (S.ws_bytes < need) {
-        if (S.ws) { HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(S.ws)); S.ws = nullptr; S.ws_bytes = 0; }
-        if (hipMalloc(&S.ws, need) != hipSuccess) return fail(c, BUSCA_ENOMEM, "cannot allocate %zu bytes of DT workspace", need);
-        S.ws_bytes = need;
-    }
+    { int rc = dtl_ws_ensure(c, dtl_ws_bytes(M, D, ES), s); if (rc) return rc; }
     char* p = (char*)S.ws;
     float* X = (float*)p; p += al(M * D * 4);
     _Float16* Xh = (_Float16*)p; p += al(M * D * 2);
-    _Float16* QKV = (_Float16*)p; p += al(M * 3 * D * 2);
-    _Float16* O = (_Float16*)p; p += al(M * D * 2);
-    _Float16* H = (_Float16*)p; p += al(M * FF * 2);
+    char* QKV = p; p += al(M * 3 * D * ES);
+    char* O = p; p += al(M * D * ES);
+    char* H = p; p += al(M * FF * ES);
     int* ids = (int*)p;
+    const void* Xop = PREC == 0 ? (const void*)X : (const void*)Xh;      // GEMM operand copy of the residual stream
     hipLaunchKernelGGL(dt_bucket_ids_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, K.mem_ltrb, K.can_ltrb, B, L, P, K.fake_f64, ids);
     DTLArgs a{};
     a.M = (int)M; a.L = L; a.P = P; a.T = T; a.E = E; a.X = X; a.Xh = Xh; a.act = K.act;
@@ -399,25 +420,33 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     a.W = S.tw.w_embed; a.K = E; a.bias = K.b_embed; a.mem_feat = K.mem_feat; a.can_feat = K.can_feat; a.ids = ids;
     a.lut_xy = K.lut_xy; a.lut_sz = K.lut_sz; a.lut_t = K.lut_t; a.lut_c = K.lut_c;
     a.tok_sep = K.tok_sep; a.tok_non = K.tok_non; a.tok_bad = K.tok_bad;
-    { int rc = dtl_gemm<D, DTL_EPI_EMBED>(c, s, a, 1); if (rc) return rc; }
+    { int rc = dtl_gemm<PREC, D, DTL_EPI_EMBED>(c, s, a, 1); if (rc) return rc; }
     for (int l = 0; l < K.nlayers; ++l) {
         const DTLayerW& W = K.layer[l];
-        a.A = Xh; a.lda = D; a.W = S.tw.w_in[l]; a.K = D; a.bias = W.b_in; a.out16 = QKV; a.ldo = 3 * D;
-        { int rc = dtl_gemm<D, DTL_EPI_QKV>(c, s, a, 3); if (rc) return rc; }
+        a.A = Xop; a.lda = D; a.W = S.tw.w_in[l]; a.K = D; a.bias = W.b_in; a.out16 = QKV; a.ldo = 3 * D;
+        { int rc = dtl_gemm<PREC, D, DTL_EPI_QKV>(c, s, a, 3); if (rc) return rc; }
         float* att = K.att ? K.att + (size_t)l * B * 4 * T * T : nullptr;
-        { int rc = dtl_attention_mt<D>(c, s, MT, QKV, O, B, T, att); if (rc) return rc; }
+        { int rc = dtl_attention_mt<PREC, D>(c, s, MT, QKV, O, B, T, att); if (rc) return rc; }
         a.A = O; a.lda = D; a.W = S.tw.w_out[l]; a.K = D; a.bias = W.b_out; a.gamma = W.g1; a.beta = W.be1;
-        { int rc = dtl_gemm<D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
-        a.A = Xh; a.lda = D; a.W = S.tw.w1[l]; a.K = D; a.bias = W.b1; a.out16 = H; a.ldo = FF;
-        { int rc = dtl_gemm<D, DTL_EPI_FFN1>(c, s, a, FF / D); if (rc) return rc; }
+        { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
+        a.A = Xop; a.lda = D; a.W = S.tw.w1[l]; a.K = D; a.bias = W.b1; a.out16 = H; a.ldo = FF;
+        { int rc = dtl_gemm<PREC, D, DTL_EPI_FFN1>(c, s, a, FF / D); if (rc) return rc; }
         a.A = H; a.lda = FF; a.W = S.tw.w2[l]; a.K = FF; a.bias = W.b2; a.gamma = W.g2; a.beta = W.be2;
-        { int rc = dtl_gemm<D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
+        { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
     }
     if (K.hidden) HIP_TRY(c, hipMemcpyAsync(K.hidden, X, M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL((dtl_decoder_kernel<D>), dim3(B), dim3(256), 0, s, (const float*)X, T, L, P, K.dec_g, K.dec_b, K.dec_w, K.dec_bias,
                        K.logits, K.probs, K.argmax);
     HIP_TRY(c, hipGetLastError());
     return BUSCA_OK;
+}
+
+extern "C" int busca_dt_reserve(busca_ctx* c, int32_t B, int32_t L, int32_t P, void* stream) {
+    if (!c) return BUSCA_EINVAL;
+    if (!c->dt.loaded) return fail(c, BUSCA_ENOWEIGHTS, "busca_dt_reserve before busca_dt_load_weights");
+    if (B < 0 || L < 1 || P < 1) return fail(c, BUSCA_EINVAL, "bad shape B=%d L=%d P=%d", B, L, P);
+    const size_t es = c->dt.cfg.precision == BUSCA_PREC_F32 ? 4 : 2;
+    return dtl_ws_ensure(c, dtl_ws_bytes((size_t)B * (L + 2 * (P + 2)), c->dt.cfg.d, es), (hipStream_t)stream);
 }
 
 extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
@@ -446,13 +475,17 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     DT_CASE(1, 2, 256, 1); DT_CASE(1, 3, 256, 1); DT_CASE(1, 4, 256, 1); DT_CASE(1, 5, 256, 1);
     DT_CASE(1, 2, 512, 1); DT_CASE(1, 3, 512, 1); DT_CASE(1, 4, 512, 2);
 #undef DT_CASE
-    if (prec == BUSCA_PREC_F16) {          // shapes beyond the fused kernel's on-chip plan: layer-wise tiled path
-        if (d == 64) return dt_forward_tiled<64>(c, K, s);
-        if (d == 256) return dt_forward_tiled<256>(c, K, s);
-        if (d == 512) return dt_forward_tiled<512>(c, K, s);
+    // shapes beyond the fused kernel's on-chip plan: layer-wise tiled path, same arithmetic type
+    if (prec == BUSCA_PREC_F16) {
+        if (d == 64) return dt_forward_tiled<1, 64>(c, K, s);
+        if (d == 256) return dt_forward_tiled<1, 256>(c, K, s);
+        if (d == 512) return dt_forward_tiled<1, 512>(c, K, s);
+    } else {
+        if (d == 64) return dt_forward_tiled<0, 64>(c, K, s);
+        if (d == 256) return dt_forward_tiled<0, 256>(c, K, s);
+        if (d == 512) return dt_forward_tiled<0, 512>(c, K, s);
     }
-    return fail(c, BUSCA_EINVAL, "no f32 Decision-Transformer kernel for T=%d (tiles %d), d=%d: the fused f32 path holds T<=48 (d<=256) "
-                                 "or T<=32 (d=512); use precision f16 for larger shapes", K.T, MT, d);
+    return fail(c, BUSCA_EINVAL, "no Decision-Transformer kernel for T=%d (tiles %d), d=%d", K.T, MT, d);
 }
 
 extern "C" int busca_dt_bucket_ids(busca_ctx* c, const float* mem_ltrb, const float* can_ltrb, int32_t B, int32_t L,

@@ -71,6 +71,12 @@ class DecisionTransformerHIP:
             _lib.ptr(out.get("hidden")), _lib.ptr(out.get("att")), s))
         return out
 
+    def reserve(self, B, L, P):
+        """Size the layer-wise path's HBM workspace for (B, L, P) now, so that no later forward allocates (busca_dt_reserve)."""
+        self._ensure_loaded()
+        s = torch.cuda.current_stream(torch.device("cuda", self.ctx.device)).cuda_stream
+        self.ctx.check(self.ctx.lib.busca_dt_reserve(self.ctx.h, int(B), int(L), int(P), s))
+
     def bucket_ids(self, mem_ltrb, can_ltrb):
         self._ensure_loaded()
         dev = torch.device("cuda", self.ctx.device)

@@ -291,12 +291,29 @@ class BUSCA:
     def associate_embeddings(self, tracks_embeddings, dets_embeddings, dists_matrix, seq_len, num_candidates,
                              use_broader_memory, select_highest_candidate, highest_candidate_minimum_thresh=None,
                              keep_highest_value=False, extra_kalman_candidates=[], plot_results=False, normalize_ims=False):
+        job = self._assoc_prepare(tracks_embeddings, dets_embeddings, dists_matrix, seq_len, num_candidates, use_broader_memory,
+                                  select_highest_candidate, highest_candidate_minimum_thresh, keep_highest_value,
+                                  extra_kalman_candidates, plot_results, normalize_ims)
+        if job is None:
+            return None, None
+        mem_feat, can_feat = self._assoc_features(job)
+        out = self._dt.forward(mem_feat, can_feat, job["mem_ltrb"], job["can_ltrb"], want_hidden=self.store_logits)
+        return self._assoc_finish(job, out)
+
+    def _assoc_prepare(self, tracks_embeddings, dets_embeddings, dists_matrix, seq_len, num_candidates, use_broader_memory,
+                       select_highest_candidate, highest_candidate_minimum_thresh=None, keep_highest_value=False,
+                       extra_kalman_candidates=(), plot_results=False, normalize_ims=False):
+        """Host bookkeeping of network.py:293-398 + the two ReID passes ENQUEUED (memory batch on the side stream, candidate
+        batch on the current one).  Returns the job (dict) that `_assoc_features` / `_assoc_finish` complete, or None for the
+        reference's early returns.  Split from the Decision-Transformer launch so that `StepBatcher` can run ONE launch for
+        the steps of several trackers."""
         B, N, P, L = len(tracks_embeddings), len(dets_embeddings), int(num_candidates), int(seq_len)
         K = len(extra_kalman_candidates)
         if B == 0 or (N == 0 and K == 0):
-            return None, None
+            return None
+        if plot_results:
+            raise NotImplementedError("plot_results needs the reference's OpenCV visualisation")
         self._sync()
-        H, W = self.expected_image_size
 
         def as_u8(img):
             img = np.asarray(img)               # DeviceCrop objects copy their real pixels back here (never placeholders)
@@ -327,6 +344,7 @@ class BUSCA:
         # the memory batch does not depend on the proposals: its ReID pass is enqueued NOW (side stream), so the host work
         # below (top-P selection, candidate lists) is hidden behind it
         mem_feat_side = self._reid_side_start(*self._gather_crops(mem_ref, as_u8, zero_is_normalised))
+        gathered = self.last_gather
 
         # top-P nearest detections per track on the GPU (ascending centre distance, ties by lower index)
         order = np.full((B, P), -1, np.int64)
@@ -364,30 +382,42 @@ class BUSCA:
             can_ltrb[..., 2:] += can_ltrb[..., :2]
 
         can_u8, can_zn = self._gather_crops(can_ref, as_u8, zero_is_normalised)
-        can_feat, mem_feat = self._reid_join(mem_feat_side, self._reid.forward(can_u8, zero_norm=can_zn))
-        mem_feat, can_feat = mem_feat.view(B, L, -1), can_feat.view(B, P, -1)     # two BN batches
-        out = self._dt.forward(mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=self.store_logits)
+        self.last_gather = (gathered[0] + self.last_gather[0], gathered[1] + self.last_gather[1])
+        can_feat = self._reid.forward(can_u8, zero_norm=can_zn)
+        return dict(B=B, N=N, K=K, P=P, L=L, order=order, n_avail=n_avail, reliable=reliable, mem_ltrb=mem_ltrb, can_ltrb=can_ltrb,
+                    mem_feat_side=mem_feat_side, can_feat=can_feat, select=bool(select_highest_candidate),
+                    thresh=highest_candidate_minimum_thresh, keep=bool(keep_highest_value))
+
+    def _assoc_features(self, job):
+        """Join the side-stream ReID batch: (mem_feat [B,L,512], can_feat [B,P,512]), the two BN batches of network.py:192-193."""
+        can_feat, mem_feat = self._reid_join(job["mem_feat_side"], job["can_feat"])
+        return mem_feat.view(job["B"], job["L"], -1), can_feat.view(job["B"], job["P"], -1)
+
+    def _assoc_finish(self, job, out):
+        """network.py:403-429: probabilities -> [B, N_det (+B)] matrix (one-hot / thresholded / raw) + reliability flags.
+        `out`: dict(probs [B,P+2], argmax [B], hidden?) of this job's tracks."""
+        B, N, K, P, L = job["B"], job["N"], job["K"], job["P"], job["L"]
         self._last = out
-        if self.store_logits:
+        if self.store_logits and "hidden" in out:
             pos = [L + 2 * j + 1 for j in range(P + 2)]
             self.logits = out["hidden"][:, pos]
             self.mem_logits = out["hidden"][:, :L].mean(dim=1)
         probs = out["probs"].cpu().numpy().astype(np.float64)
         best = out["argmax"].cpu().numpy()
-
         cols = N if K == 0 else N + K
         probs_matrix = np.zeros((B, cols))
         rows = np.arange(B)
-        if select_highest_candidate:
+        if job["select"]:
             top = probs[rows, best]
-            th = highest_candidate_minimum_thresh
+            th = job["thresh"]
             ok = np.ones(B, bool) if (th is None or th == 0) else ((th > 0.0) & (top >= th))
             picked = np.zeros_like(probs)
-            picked[rows[ok], best[ok]] = top[ok] if keep_highest_value else 1.0
+            picked[rows[ok], best[ok]] = top[ok] if job["keep"] else 1.0
             probs = picked
+        order, n_avail = job["order"], job["n_avail"]
         for t in range(B):
             probs_matrix[t, order[t, :n_avail]] = probs[t, :n_avail]
-        return probs_matrix, reliable
+        return probs_matrix, job["reliable"]
 
     def _gather_crops(self, refs, as_u8, zero_is_normalised=False):
         """[B][n] crop references (None = all-zero crop) -> (cuda u8 [B*n,384,128,3], zero flags | None) with ONE index-gather

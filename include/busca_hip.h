@@ -94,6 +94,13 @@ int busca_dt_forward(busca_ctx* ctx, const float* mem_feat, const float* can_fea
                      const float* can_ltrb, int32_t B, int32_t L, int32_t P, float* logits, float* probs,
                      int32_t* argmax, float* hidden, float* att, void* stream);
 
+/* Shapes beyond the fused kernel's on-chip plan (T > 80, d = 512 with T > 64 in f16; T > 48 / 32 in f32) run layer by layer
+ * with activations in a context-owned HBM workspace.  busca_dt_reserve sizes that workspace for (B, L, P) ahead of time, so
+ * that no forward allocates; without it the first forward of a larger shape grows the workspace itself (one stream
+ * synchronisation + hipMalloc).  Both precisions are served: the f32 flavour keeps the reference's arithmetic
+ * (busca/custom_layers.py:30-41 computes every shape in float32). */
+int busca_dt_reserve(busca_ctx* ctx, int32_t B, int32_t L, int32_t P, void* stream);
+
 /* Bucket indices only (busca/encodings.py:150-235): ids [B,T,3] i32 = (xy, size, time) per token. */
 int busca_dt_bucket_ids(busca_ctx* ctx, const float* mem_ltrb, const float* can_ltrb, int32_t B, int32_t L,
                         int32_t P, int32_t* ids, void* stream);

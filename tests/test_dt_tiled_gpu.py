@@ -12,6 +12,7 @@ from busca_amd import synth
 pytestmark = pytest.mark.gpu
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dt_*.npz")))
 TOL = dict(logit=6e-2, prob=5e-3, att=5e-3, hidden=8e-2, margin=2e-2)     # f16-operand tolerances (as test_dt_gpu.py)
+TOL32 = dict(logit=2e-4, prob=2e-5, att=2e-5, hidden=5e-4, margin=1e-4)   # float32 tolerances of test_dt_gpu.py
 
 
 @pytest.fixture(scope="module")
@@ -31,14 +32,16 @@ def force_tiled():
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
 @pytest.mark.parametrize("mode", ["f64", "f32"])
-def test_tiled_vs_reference_golden(ctx, force_tiled, path, mode):
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_tiled_vs_reference_golden(ctx, force_tiled, path, mode, prec):
     from busca_amd.dt import DecisionTransformerHIP
+    TOL = TOL32 if prec == "f32" else globals()["TOL"]
     g = np.load(path)
     d, ff, B, L, P, seed = (int(g[k]) for k in ("d", "ff", "B", "L", "P", "seed"))
     sd = synth.dt_state_dict(seed, d=d, ff=ff)
     inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4 if B <= 8 else 16)
     has_att = ("att_" + mode) in g
-    m = DecisionTransformerHIP(ctx, sd, fake_bbox_f64=(mode == "f64"), precision="f16")
+    m = DecisionTransformerHIP(ctx, sd, fake_bbox_f64=(mode == "f64"), precision=prec)
     out = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"], want_hidden=True, want_att=has_att)
     torch.cuda.synchronize()
     out = {k: v.cpu().numpy() for k, v in out.items()}
@@ -57,15 +60,20 @@ def test_tiled_vs_reference_golden(ctx, force_tiled, path, mode):
 
 @pytest.mark.parametrize("shape", [(128, 11, 32, 512), (24, 11, 64, 512), (40, 11, 40, 256), (9, 11, 62, 64)],
                          ids=["cfg4_128x32_d512", "cfg5_shape_x64_d512", "T95_d256", "T139_d64"])
-def test_tiled_large_shapes_vs_oracle(ctx, shape):
-    """Shapes the fused kernel cannot hold (dispatch picks the tiled path by itself)."""
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_tiled_large_shapes_vs_oracle(ctx, shape, prec):
+    """Shapes the fused kernel cannot hold (dispatch picks the tiled path by itself), in both arithmetic types: the f32
+    flavour (v_mfma_f32_16x16x4_f32, the reference's own precision, busca/custom_layers.py:30-41) to the float32
+    tolerances of test_dt_gpu.py - BASELINE configs[3] (128 x 32, T = 79) at reference precision."""
     from busca_amd.dt import DecisionTransformerHIP
     from oracle import dt as odt
+    TOL = TOL32 if prec == "f32" else globals()["TOL"]
     B, L, P, d = shape
     seed = 300 + P + d
     sd = synth.dt_state_dict(seed, d=d, ff=2 * d)
     inp = synth.dt_inputs(seed, B, L, P, sentinel_every=8)
-    m = DecisionTransformerHIP(ctx, sd, precision="f16")
+    m = DecisionTransformerHIP(ctx, sd, precision=prec)
+    m.reserve(B, L, P)                                   # workspace sized ahead of time: the forward does not allocate
     out = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])
     torch.cuda.synchronize()
     out = {k: v.cpu().numpy() for k, v in out.items()}
@@ -78,11 +86,13 @@ def test_tiled_large_shapes_vs_oracle(ctx, shape):
     assert (out["argmax"][clear] == ref["argmax"].numpy()[clear]).all()
 
 
-def test_f32_large_shape_is_refused_loudly(ctx):
+def test_unsupported_shape_is_refused_loudly(ctx):
+    """More than 144 tokens per track is beyond every path: a BuscaError, never a silent fallback."""
     from busca_amd import _lib
     from busca_amd.dt import DecisionTransformerHIP
     sd = synth.dt_state_dict(1, d=256, ff=512)
-    inp = synth.dt_inputs(1, 2, 11, 40)
-    m = DecisionTransformerHIP(ctx, sd, precision="f32")
-    with pytest.raises(_lib.BuscaError):
-        m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])
+    inp = synth.dt_inputs(1, 2, 11, 70)
+    for prec in ("f32", "f16"):
+        m = DecisionTransformerHIP(ctx, sd, precision=prec)
+        with pytest.raises(_lib.BuscaError):
+            m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])
