@@ -34,6 +34,7 @@ SIGNATURES = {
     "busca_pairwise": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "busca_topk_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "busca_coverage": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "busca_ecc_align": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_double, _vp, C.POINTER(C.c_double), C.POINTER(_i32), _vp]),
     "busca_kalman_multi_predict": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "busca_duplicate_masks": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, C.c_double, _vp, _vp, _vp]),
     "busca_crop_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),

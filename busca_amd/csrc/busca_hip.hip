@@ -24,6 +24,7 @@
 #include "reid_halo.hip.inc"
 #include "reid_f32.hip.inc"
 #include "dt_tiled.hip.inc"
+#include "ecc_kernel.hip.inc"
 
 // ---------------------------------------------------------------------------------------------------------
 struct DTTiledW {                   // row-major copies of the matrices for the tiled path, in the operand type (f16 or f32)
@@ -56,6 +57,7 @@ struct busca_ctx {
     int* crop_fill = nullptr;      // per-crop pad value scratch (busca_crop_gather)
     int crop_fill_cap = 0;
     std::set<const void*> lds_configured;   // kernels whose dynamic-LDS limit was raised on THIS device
+    void* ecc_ws = nullptr; size_t ecc_ws_bytes = 0;    // busca_ecc_align scratch: 5 float images + partials
 };
 
 // Raise a kernel's dynamic LDS limit once per context (the attribute is per device, so a process driving several
@@ -129,6 +131,7 @@ extern "C" void busca_ctx_destroy(busca_ctx* c) {
     if (c->dt.dev_tiled) hipFree(c->dt.dev_tiled);
     if (c->dt.ws) hipFree(c->dt.ws);
     if (c->crop_fill) hipFree(c->crop_fill);
+    if (c->ecc_ws) hipFree(c->ecc_ws);
     reid_free(c->reid);
     delete c;
 }

@@ -294,6 +294,58 @@ def is_reliable(frame_shape, active_stracks, p, ctx=None):
     return bool(cov["area_covered"] > cov["area_covered_per_obj"] * p[0] + p[1])
 
 
+def find_transform_ecc(prev_frame, cur_frame, warp_matrix=None, motion="MOTION_EUCLIDEAN", number_of_iterations=100,
+                       termination_eps=1e-5, ctx=None):
+    """cv2.cvtColor(BGR2GRAY) + cv2.findTransformECC(templateImage=prev, inputImage=cur, ...) on the GPU (busca_ecc_align;
+    third-party OpenCV arithmetic restated, see oracle/ecc.py).  Frames: u8 BGR [H,W,3] (numpy or cuda tensors).
+    Returns (cc, warp float32 [2,3]); raises BuscaError where OpenCV raises (no convergence / NaN)."""
+    import ctypes as C
+    ctx = ctx or geometry.default_context()
+    dev = torch.device("cuda", ctx.device)
+    if motion not in ("MOTION_EUCLIDEAN", "MOTION_AFFINE"):
+        raise ValueError("Invalid warp_mode: {}".format(motion))
+    fr = []
+    for f in (prev_frame, cur_frame):
+        if not torch.is_tensor(f):
+            f = torch.from_numpy(np.ascontiguousarray(f))
+        f = f.to(dev).contiguous()
+        assert f.dtype == torch.uint8 and f.dim() == 3 and f.shape[2] == 3
+        fr.append(f)
+    assert fr[0].shape == fr[1].shape
+    H, W = fr[0].shape[:2]
+    warp = np.eye(2, 3, dtype=np.float32) if warp_matrix is None else np.ascontiguousarray(warp_matrix, dtype=np.float32).reshape(2, 3).copy()
+    cc, iters = C.c_double(0.0), C.c_int32(0)
+    ctx.check(ctx.lib.busca_ecc_align(ctx.h, fr[0].data_ptr(), fr[1].data_ptr(), H, W, fr[0].stride(0), fr[1].stride(0),
+                                      0 if motion == "MOTION_EUCLIDEAN" else 1, int(number_of_iterations), float(termination_eps),
+                                      warp.ctypes.data, C.byref(cc), C.byref(iters), torch.cuda.current_stream(dev).cuda_stream))
+    find_transform_ecc.last_iterations = iters.value
+    return cc.value, warp
+
+
+def warp_pos(pos, warp_matrix):
+    """BYTETracker.warp_pos (byte_tracker.py:653-657): float32 [2,3] @ [x, y, 1]."""
+    p = np.array([pos[0], pos[1], 1.0], dtype=np.float32)
+    return (np.asarray(warp_matrix, dtype=np.float32).reshape(2, 3) @ p).astype(np.float32)
+
+
+def camera_motion_compensation(track_pool, last_image, current_frame, frame_id=2, number_of_iterations=100, termination_eps=0.00001,
+                               warp_mode="MOTION_EUCLIDEAN", ctx=None):
+    """BYTETracker.camera_motion_compensation (byte_tracker.py:626-650): estimate the previous->current frame warp and move every
+    track of `track_pool` by it (`STrack.apply_camera_motion`, :123-137: position (mean[:2] or _tlwh[:2]) * scale -> warp ->
+    / scale).  Returns the correlation coefficient (1.0 on the first frame, as the reference does)."""
+    cc = 1.0
+    if frame_id > 1 and last_image is not None:
+        cc, warp = find_transform_ecc(last_image, current_frame, None, warp_mode, number_of_iterations, termination_eps, ctx=ctx)
+        for t in track_pool:
+            if hasattr(t, "apply_camera_motion"):
+                t.apply_camera_motion(warp)
+                continue
+            holder = t.mean if getattr(t, "mean", None) is not None else t._tlwh
+            new_pos = warp_pos(np.asarray(holder[:2], dtype=np.float64) * t.scale, warp) / t.scale
+            holder[:2] = new_pos
+    return cc
+
+
 def recover_with_busca(probs_matrix, reliable, n_dets, busca_thresh):
     """Caller-side decision rule shared by the adapters (byte_tracker.py:504-527, StrongSORT tracker.py:347-371,
     GHOST tracker.py:776-800): lost track i is recovered at its own Kalman prediction iff its memory is reliable

@@ -133,6 +133,17 @@ int busca_topk_rows(busca_ctx* ctx, const double* dist, int32_t B, int32_t N, in
  * corner pixels included). */
 int busca_coverage(busca_ctx* ctx, const int32_t* rects, int32_t n, int32_t H, int32_t W, uint64_t* count, void* stream);
 
+/* Camera-motion compensation (adapters/ByteTrack/yolox/tracker/byte_tracker.py:626-650): cv2.cvtColor(BGR2GRAY) of both frames
+ * + cv2.findTransformECC(templateImage = previous, inputImage = current, warpMatrix, motionType, (EPS | COUNT, max_iters, eps))
+ * with the default 5x5 Gaussian pre-filter.  prev / cur: dev u8 [H,W,3] BGR (row strides in bytes).  motion 0 = MOTION_EUCLIDEAN,
+ * 1 = MOTION_AFFINE.  warp: HOST float32 [6], row-major 2x3, in = initial guess (identity in the reference), out = estimate.
+ * *cc (host) = the enhanced correlation coefficient the reference returns, *iters (host, may be NULL) = iterations run.
+ * The per-iteration image work (warp, Jacobian, all reductions) runs on the GPU; the 3x3 / 6x6 solve between iterations on
+ * the host, so this call SYNCHRONISES `stream` once per iteration.  Errors where OpenCV raises StsNoConv return BUSCA_EINVAL.
+ * Third-party arithmetic (opencv_python 4.7.0.72) restated from the published algorithm: parity unpinned (oracle/ecc.py). */
+int busca_ecc_align(busca_ctx* ctx, const uint8_t* prev, const uint8_t* cur, int32_t H, int32_t W, int32_t stride_prev, int32_t stride_cur,
+                    int32_t motion, int32_t max_iters, double eps, float* warp, double* cc, int32_t* iters, void* stream);
+
 /* ---- track state of the association rounds ------------------------------------------------ */
 /* STrack.multi_predict (adapters/ByteTrack/yolox/tracker/byte_tracker.py:50-61): constant-velocity Kalman prediction
  * of n tracks in place.  mean dev f64 [n,8] (x,y,a,h,vx,vy,va,vh), cov dev f64 [n,8,8]; not_tracked dev u8 [n] or NULL:

@@ -22,7 +22,9 @@ def _model():
 
 
 def _targs(busca_thresh):
-    return types.SimpleNamespace(seq_len=11, num_candidates=5, use_broader_memory=True, select_highest_candidate=True,
+    # raw probabilities (not the one-hot winner): with random weights the argmax is arbitrary, a tiny threshold on the raw
+    # probability of the track's own prediction still exercises the whole recovery path
+    return types.SimpleNamespace(seq_len=11, num_candidates=5, use_broader_memory=True, select_highest_candidate=False,
                                  busca_thresh=busca_thresh, match_thresh=0.8, track_thresh=0.5, det_thresh=0.1, max_time_lost=30)
 
 

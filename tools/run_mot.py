@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--compare-with")
     ap.add_argument("--busca-thresh", type=float)
     ap.add_argument("--max-frames", type=int)
+    ap.add_argument("--raw-probs", action="store_true", help="select_highest_candidate=False (thresholds the raw probability)")
     a = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -64,7 +65,7 @@ def main():
 
     targ = types.SimpleNamespace(seq_len=getattr(targs, "seq_len", 11), num_candidates=getattr(targs, "num_candidates", 5),
                                  use_broader_memory=getattr(targs, "use_broader_memory", True),
-                                 select_highest_candidate=getattr(targs, "select_highest_candidate", True),
+                                 select_highest_candidate=False if a.raw_probs else getattr(targs, "select_highest_candidate", True),
                                  busca_thresh=a.busca_thresh if a.busca_thresh is not None else getattr(targs, "busca_thresh", 0.5),
                                  match_thresh=0.8, track_thresh=0.5, det_thresh=0.1, max_time_lost=30)
     factory = None
