@@ -306,11 +306,12 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int PREC, int MT, int D, int FF, int NCH>
+template <int PREC, int MT, int D, int FF, int NCH, int NTRK = 1, int OCC2 = 0>
 static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
-    typedef DTLds<PREC, MT, D, FF, 512, NCH> LD;
-    static_assert(LD::TOTAL <= 160 * 1024, "LDS plan exceeds 160 KiB");
-    auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH>;
+    typedef DTLds<PREC, MT, D, FF, 512, NCH, NTRK> LD;
+    static_assert(LD::TOTAL <= 160 * 1024 / (OCC2 ? 2 : 1), "LDS plan exceeds the per-workgroup share of the 160 KiB");
+    auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH, NTRK, OCC2>;
+    const int nwg = (P.B + NTRK - 1) / NTRK;
     { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
     static const bool prof = getenv("BUSCA_DT_PROF") != nullptr;   // debug: phase timestamps of workgroup 0
     if (prof) {
@@ -319,12 +320,12 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
         HIP_TRY(c, hipMalloc((void**)&d, 4 * DT_PROF_SLOTS * sizeof(long long)));
         HIP_TRY(c, hipMemset(d, 0, 4 * DT_PROF_SLOTS * sizeof(long long)));
         Q.prof = d;
-        hipLaunchKernelGGL(kern, dim3(P.B), dim3(256), LD::TOTAL, s, Q);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LD::TOTAL, s, Q);
         HIP_TRY(c, hipStreamSynchronize(s));
         long long h[4 * DT_PROF_SLOTS];
         HIP_TRY(c, hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipFree(d));
-        fprintf(stderr, "DT_PROF grid=%d:", P.B);
+        fprintf(stderr, "DT_PROF grid=%d:", nwg);
         for (int w = 0; w < 4; ++w) {
             fprintf(stderr, "\n w%d", w);
             for (int i = 1; i < DT_PROF_SLOTS; ++i)
@@ -335,7 +336,7 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
     }
     {
         TimedLaunch tl(c, s);
-        hipLaunchKernelGGL(kern, dim3(P.B), dim3(256), LD::TOTAL, s, P);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LD::TOTAL, s, P);
     }
     HIP_TRY(c, hipGetLastError());
     return BUSCA_OK;
@@ -469,6 +470,15 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     hipStream_t s = (hipStream_t)stream;
     const bool force_tiled = getenv("BUSCA_DT_TILED") != nullptr;          // testing: run the layer-wise path on any shape
     const bool fused_ok = !force_tiled && P + 2 <= 64;
+    // f16: the fused kernel is bound by its weight stream, so from two rounds of workgroups on (B > 256 CUs) every workgroup
+    // takes TWO tracks and each streamed weight fragment feeds twice the tokens (BUSCA_DT_NTRK=1/2 forces either)
+    static const int ntrk_env = getenv("BUSCA_DT_NTRK") ? atoi(getenv("BUSCA_DT_NTRK")) : 0;
+    const bool two = ntrk_env == 2 || (ntrk_env == 0 && B > 256);
+#define DT_CASE2(M, DD, NCH) if (fused_ok && two && prec == 1 && MT == M && d == DD) return dt_launch<1, M, DD, 2 * DD, NCH, 2>(c, K, s)
+    DT_CASE2(3, 256, 1); DT_CASE2(2, 256, 1);        // d = 512: the parked f32 residual does not fit the LDS plan
+#undef DT_CASE2
+    static const int occ2_env = getenv("BUSCA_DT_OCC2") ? atoi(getenv("BUSCA_DT_OCC2")) : 0;
+    if (fused_ok && occ2_env && prec == 1 && MT == 3 && d == 256) return dt_launch<1, 3, 256, 512, 1, 1, 1>(c, K, s);
 #define DT_CASE(PR, M, DD, NCH) if (fused_ok && prec == PR && MT == M && d == DD) return dt_launch<PR, M, DD, 2 * DD, NCH>(c, K, s)
     DT_CASE(0, 1, 64, 1); DT_CASE(0, 1, 256, 1); DT_CASE(0, 1, 512, 1); DT_CASE(1, 1, 64, 1); DT_CASE(1, 1, 256, 1); DT_CASE(1, 1, 512, 1);
     DT_CASE(0, 2, 64, 1); DT_CASE(0, 3, 64, 1); DT_CASE(0, 4, 64, 1);

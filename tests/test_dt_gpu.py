@@ -136,3 +136,27 @@ def test_dt_batch_invariance(ctx):
     sub = {k: v[10:13] for k, v in inp.items()}
     part = m.forward(sub["mem_feat"], sub["can_feat"], sub["mem_boxes"], sub["can_boxes"])
     assert np.array_equal(part["logits"].cpu().numpy(), full["logits"][10:13])
+
+
+@pytest.mark.parametrize("shape", [(37, 11, 16, 256), (300, 11, 16, 256), (33, 11, 5, 512), (5, 11, 5, 256)])
+def test_two_tracks_per_workgroup_flavour(ctx, monkeypatch, shape):
+    """f16 flavour with TWO tracks per workgroup (each streamed weight fragment feeds both; automatic from B > 256): same
+    results as one track per workgroup up to the float32 association of the residual add, inside the f16 tolerances against
+    the oracle, odd track counts included (the last workgroup's second slot recomputes the last track and stores nothing)."""
+    from oracle import dt as odt
+    B, L, P, d = shape
+    seed = 400 + B + d
+    sd = synth.dt_state_dict(seed, d=d, ff=2 * d)
+    inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)
+    monkeypatch.setenv("BUSCA_DT_NTRK", "1")
+    one, _ = _run(ctx, sd, inp, "f16", True, want_hidden=True, want_att=True)
+    monkeypatch.setenv("BUSCA_DT_NTRK", "2")
+    two, _ = _run(ctx, sd, inp, "f16", True, want_hidden=True, want_att=True)
+    assert np.abs(one["logits"] - two["logits"]).max() <= 2e-3
+    assert np.abs(one["att"] - two["att"]).max() <= 1e-4 and np.abs(one["hidden"] - two["hidden"]).max() <= 2e-3
+    assert (two["argmax"] == two["probs"].argmax(-1)).all()
+    ref = odt.dt_forward(sd, odt.DTConfig(d=d, ff=2 * d), **inp, return_all=True)
+    tol = TOL["f16"]
+    assert np.abs(two["logits"] - ref["logits"].numpy()).max() <= tol["logit"]
+    assert np.abs(two["probs"] - ref["probs"].numpy()).max() <= tol["prob"]
+    monkeypatch.delenv("BUSCA_DT_NTRK")

@@ -45,8 +45,11 @@ def test_ecc_matches_oracle(motion):
         rho, Wo, trace = ecc.find_transform_ecc(ecc.bgr2gray(im1), ecc.bgr2gray(im2), motion=motion[7:].lower(), return_trace=True)
         assert tracking.find_transform_ecc.last_iterations == len(trace)
         assert abs(cc - rho) < 1e-5, (cc, rho)
-        assert np.abs(W - Wo).max() < 2e-4, np.abs(W - Wo).max()          # same iterates, float32 round-off apart
-        assert np.abs(W - M).max() < 0.05                                   # and both sit on the true transform
+        # same iterates, float32 round-off apart.  theta (about the frame origin) and the translation are strongly coupled,
+        # so the comparison is on where the warps send points of the frame: < 0.01 px anywhere
+        pts = np.array([[x, y, 1.0] for x in (0, 80, 159) for y in (0, 60, 119)]).T
+        assert np.abs(W.astype(np.float64) @ pts - Wo.astype(np.float64) @ pts).max() < 1e-2
+        assert np.abs(W.astype(np.float64) @ pts - M @ pts).max() < 0.1    # and both sit on the true transform
 
 
 @pytest.mark.gpu
