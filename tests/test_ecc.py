@@ -37,19 +37,30 @@ def test_oracle_recovers_known_transform():
 @pytest.mark.gpu
 @pytest.mark.parametrize("motion", ["MOTION_EUCLIDEAN", "MOTION_AFFINE"])
 def test_ecc_matches_oracle(motion):
+    """Iterate by iterate: after k = 1..6 iterations (termination test off) the kernel's warp and correlation coefficient equal
+    the oracle's to float32 round-off.  The free-running call (eps 1e-5, <= 100 iterations, the reference's settings) is then
+    compared on what matters - where the warp sends points - because near the optimum the rho increments hover around the
+    termination threshold and round-off decides at which iteration the loop stops (and, for the affine model on a
+    near-identity pair, the iterates themselves separate after ~20 iterations)."""
     from busca_amd import tracking
     from oracle import ecc
+    pts = np.array([[x, y, 1.0] for x in (0, 80, 159) for y in (0, 60, 119)]).T
     for seed, (th, tx, ty) in enumerate([(0.01, 2.3, -1.4), (-0.02, -3.1, 0.8), (0.0, 0.4, 0.2)]):
         im1, im2, M = _pair(th=th, tx=tx, ty=ty, seed=seed)
-        cc, W = tracking.find_transform_ecc(im1, im2, motion=motion)
-        rho, Wo, trace = ecc.find_transform_ecc(ecc.bgr2gray(im1), ecc.bgr2gray(im2), motion=motion[7:].lower(), return_trace=True)
-        assert tracking.find_transform_ecc.last_iterations == len(trace)
-        assert abs(cc - rho) < 1e-5, (cc, rho)
-        # same iterates, float32 round-off apart.  theta (about the frame origin) and the translation are strongly coupled,
-        # so the comparison is on where the warps send points of the frame: < 0.01 px anywhere
-        pts = np.array([[x, y, 1.0] for x in (0, 80, 159) for y in (0, 60, 119)]).T
-        assert np.abs(W.astype(np.float64) @ pts - Wo.astype(np.float64) @ pts).max() < 1e-2
-        assert np.abs(W.astype(np.float64) @ pts - M @ pts).max() < 0.1    # and both sit on the true transform
+        g1, g2 = ecc.bgr2gray(im1), ecc.bgr2gray(im2)
+        _, _, trace = ecc.find_transform_ecc(g1, g2, motion=motion[7:].lower(), iters=6, eps=-1.0, return_trace=True)
+        for k in (1, 2, 4, 6):
+            cc, W = tracking.find_transform_ecc(im1, im2, motion=motion, number_of_iterations=k, termination_eps=-1.0)
+            rho_k, W_k = trace[k - 1]
+            assert tracking.find_transform_ecc.last_iterations == k
+            assert abs(cc - rho_k) < 1e-5, (seed, k, cc, rho_k)
+            assert np.abs(W - W_k).max() < 2e-5, (seed, k, np.abs(W - W_k).max())
+        cc, W = tracking.find_transform_ecc(im1, im2, motion=motion)                  # the reference's settings
+        rho, Wo = ecc.find_transform_ecc(g1, g2, motion=motion[7:].lower())
+        assert cc > 0.99 and rho > 0.99
+        lim = 0.1 if motion == "MOTION_EUCLIDEAN" else 0.25
+        assert np.abs(W.astype(np.float64) @ pts - M @ pts).max() < lim               # both sit on the true transform
+        assert np.abs(Wo.astype(np.float64) @ pts - M @ pts).max() < lim
 
 
 @pytest.mark.gpu
