@@ -108,3 +108,25 @@ def test_kernel_timing_facility(ctx):
     lib.busca_timing_read(h, C.byref(avg), C.byref(n), 1)
     lib.busca_timing_enable(h, 0)
     assert n.value == 5 and 0 < avg.value < 5.0
+
+
+def test_cfg4_full_step_on_gpu_crops():
+    """BASELINE configs[3] (MOT20 dense crowd: 128 lost x 32 proposals, crops cut and gathered on the GPU, BatchNorm batches of
+    1 408 and 4 096 crops, T = 79 tokens): the whole step runs; the Decision-Transformer leg is checked against the oracle on
+    the features the HIP extractor produced (the extractor itself is oracle-checked at 352 / 512 crops in test_reid_gpu.py -
+    4 096 crops are 33 TFLOP on the CPU), features are unit vectors, and the step is deterministic."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import cfg4_step
+    from oracle import dt as odt
+    a = cfg4_step.run(1, "f16", check=True)
+    b = cfg4_step.run(1, "f16", check=True)
+    assert np.array_equal(a["_out"]["probs"], b["_out"]["probs"]) and np.array_equal(a["_feat"][1], b["_feat"][1])
+    mf, cf = a["_feat"]
+    assert mf.shape == (128, 11, 512) and cf.shape == (128, 32, 512)
+    assert np.allclose(np.linalg.norm(cf, axis=-1), 1.0, atol=1e-4) and np.isfinite(mf).all()
+    inp = a["_inp"]
+    ref = odt.dt_forward(a["_sd"], odt.DTConfig(d=512, ff=1024), mf, cf, inp["mem_boxes"], inp["can_boxes"], return_all=True)
+    assert np.abs(a["_out"]["probs"] - ref["probs"].numpy()).max() <= 5e-3
+    assert np.abs(a["_out"]["logits"] - ref["logits"].numpy()).max() <= 6e-2
+    assert a["crops_per_step"] == 128 * 43

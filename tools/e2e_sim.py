@@ -43,6 +43,44 @@ def run(lost=32, n_obj=150, P=5, d=512, precision="f16", frames=30, verbose=True
     return res
 
 
+def run_multi(n_seq=4, lost=8, n_obj=60, P=5, d=512, precision="f16", frames=20):
+    """S tracker instances (sequences sharded onto this GPU) stepping in the same frame interval: S separate
+    associate_embeddings calls versus the same S steps through busca_amd.batcher.StepBatcher (one Decision-Transformer launch
+    per interval; every step keeps its own two ReID BatchNorm batches).  Returns per-interval p50 times and checks equality."""
+    from busca_amd.batcher import StepBatcher
+    args = types.SimpleNamespace(num_layer=4, nhead=4, dim_embedding=512, trans_dim=d, ff_size=2 * d, activation="gelu", dropout_p=0.1,
+                                 input_flavour="MEM-SEP-CAN-BAD", output_flavour="CAN", encode_separator_as_reference=True,
+                                 encode_special_tokens=False, reid_weights_file="no", device=torch.device("cuda:0"), precision=precision, seed=7)
+    model = BUSCA(args).to(torch.device("cuda:0")).eval()
+    scenes = [SimScene(model, n_objects=n_obj, seed=7 + 13 * i) for i in range(n_seq)]
+    for sc in scenes:
+        sc.warm_up(12)
+    batcher = StepBatcher(model)
+    t_seq, t_bat, same = [], [], True
+    for f in range(frames + 3):
+        steps = []
+        for sc in scenes:
+            lost_t, dets, kal = sc.step_inputs(lost)
+            steps.append((lost_t, dets, center_distance(lost_t, dets), kal))
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        single = [model.associate_embeddings(l, dd, ds, 11, P, True, True, extra_kalman_candidates=k, normalize_ims=True) for l, dd, ds, k in steps]
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        tickets = [batcher.submit(l, dd, ds, 11, P, True, True, extra_kalman_candidates=k, normalize_ims=True) for l, dd, ds, k in steps]
+        batcher.flush()
+        batched = [t.result() for t in tickets]
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        same = same and all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(single, batched))
+        if f >= 3:
+            t_seq.append(b - a); t_bat.append(c - b)
+    return dict(sequences=n_seq, lost=lost, dets=n_obj - lost, proposals=P, d=d, precision=precision,
+                p50_interval_ms_separate_calls=float(np.percentile(t_seq, 50) * 1e3), p50_interval_ms_step_batcher=float(np.percentile(t_bat, 50) * 1e3),
+                steps_per_s_separate_calls=float(n_seq / np.mean(t_seq)), steps_per_s_step_batcher=float(n_seq / np.mean(t_bat)),
+                dt_launches_per_interval=1, bit_identical=bool(same))
+
+
 if __name__ == "__main__":
     a = sys.argv[1:]
     run(int(a[0]) if a else 32, int(a[1]) if len(a) > 1 else 150, int(a[2]) if len(a) > 2 else 5, int(a[3]) if len(a) > 3 else 512,
