@@ -196,12 +196,24 @@ def config_leg(ctx, dev, name, B, L, P, d, precision, F, steps, seed=7):
                                      kernel="dt_fused_kernel" if fused else "dtl_gemm_kernel + dtl_attention_kernel (whole forward)")}
 
 
-def full_step(ctx, dt_model, B, L, P, n_steps, dev):
-    """ReID (two train-mode-BN batches: B*L memory crops, B*P candidate crops, u8 resident in HBM) + DT."""
+def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None):
+    """ReID (two train-mode-BN batches: B*L memory crops, B*P candidate crops, u8 resident in HBM) + DT.
+    n_det=None: every candidate slot holds a different crop (worst case).  n_det=k: the B*P candidate slots are filled from k
+    distinct detection crops, as a tracker's are (each track takes its P nearest detections, network.py:340-358); the extractor
+    then computes each distinct crop once and weights the BatchNorm statistics by its multiplicity (busca_reid_forward_w)."""
     from busca_amd.reid import ReIDEncoderHIP
     reid = ReIDEncoderHIP(ctx, synth.reid_state_dict(7))
     mem = torch.from_numpy(synth.randint_u8(11, "mem", (B * L, 384, 128, 3))).to(dev)
-    can = torch.from_numpy(synth.randint_u8(12, "can", (B * P, 384, 128, 3))).to(dev)
+    inverse_d, counts = None, None
+    if n_det is None:
+        can = torch.from_numpy(synth.randint_u8(12, "can", (B * P, 384, 128, 3))).to(dev)
+    else:
+        can = torch.from_numpy(synth.randint_u8(12, "can", (n_det, 384, 128, 3))).to(dev)
+        rng = np.random.default_rng(12)
+        inverse = np.concatenate([rng.permutation(n_det)[:P] for _ in range(B)])
+        u, first, inv, counts = np.unique(inverse, return_index=True, return_inverse=True, return_counts=True)
+        o = np.argsort(first, kind="stable"); rank = np.empty_like(o); rank[o] = np.arange(len(o))
+        can, counts, inverse_d = can[torch.from_numpy(u[o]).to(dev)].contiguous(), counts[o], torch.from_numpy(rank[inv]).to(dev)
     boxes = synth.dt_inputs(7, B, L, P)
     mb, cb = torch.from_numpy(boxes["mem_boxes"]).to(dev), torch.from_numpy(boxes["can_boxes"]).to(dev)
 
@@ -211,7 +223,8 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev):
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            cf = reid.forward(can, stream=side.cuda_stream).view(B, P, -1)
+            cf = reid.forward(can, stream=side.cuda_stream, weights=counts)
+            cf = (cf if inverse_d is None else cf[inverse_d]).view(B, P, -1)
         mf = reid.forward(mem).view(B, L, -1)
         cur.wait_stream(side)
         return dt_model.forward(mf, cf, mb, cb)
@@ -223,7 +236,8 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev):
         one()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / n_steps
-    crops = B * (L + P)
+    slots = B * (L + P)
+    crops = B * L + int(can.shape[0])               # crops the extractor really computes
     tf = crops * REID_GFLOP_PER_CROP * 1e9 / dt / 1e12
     traffic = None
     try:    # HBM bytes of the two ReID passes from the committed PMC runs, scaled per crop from the nearest measured batch
@@ -232,7 +246,8 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev):
         traffic = per_crop * crops
     except Exception:
         traffic = None
-    return {"value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "crops_per_step": crops,
+    return {"value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "crop_slots_per_step": slots, "crops_per_step": crops,
+            "candidate_crops": "all distinct" if n_det is None else "%d slots drawn from %d detections (repeats computed once, weighted statistics)" % (B * P, n_det),
             "reid_algorithmic_tflop_per_step": crops * REID_GFLOP_PER_CROP / 1e3,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["f16"], "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS["f16"],
                          "traffic": traffic, "hbm_time_floor_ms": (traffic / 6.3e12 * 1e3) if traffic else None,
@@ -390,12 +405,14 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import cfg4_step
             cfgs["cfg4_full_step"] = cfg4_step.run(3, "f16")
+            cfgs["cfg4_full_step_expanded_batch"] = cfg4_step.run(3, "f16", dedup=False)
         except Exception as e:
             cfgs["cfg4_full_step"] = {"error": repr(e)}
         result["configs"] = cfgs
         if args.full_steps > 0:
             f16_model = r2.model if other == "f16" else DTRunner(ctx, sd, "f16", tens, B, L, P, 1, dev).model
             result["full_step"] = full_step(ctx, f16_model, B, L, P, args.full_steps, dev)
+            result["full_step_tracker_like_candidates"] = full_step(ctx, f16_model, B, L, P, args.full_steps, dev, n_det=118)
     if rank == 0:
         if args.cpu_seconds > 0:
             one = {k: v[:B] for k, v in big.items()}

@@ -41,6 +41,7 @@ SIGNATURES = {
     "busca_crop_gather_ex": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "busca_gather_crops": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "busca_reid_forward_ex": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "busca_reid_forward_w": (C.c_int, [_vp, _vp, _i32, _vp, _vp, C.c_double, _vp, _vp]),
     "busca_reid_blob_floats": (_sz, []),
     "busca_reid_load_weights": (C.c_int, [_vp, _vp, _sz]),
     "busca_reid_load_weights_ex": (C.c_int, [_vp, _vp, _sz, _i32]),

@@ -75,6 +75,9 @@ class BUSCA:
         # True: get_image_crops(normalize=False) keeps the crops in the device pool only; host reads copy them back on demand
         self.device_only_crops = bool(getattr(args, "device_only_crops", False))
         self.store_logits = False           # set True to fill .logits / .mem_logits like the reference does
+        # True: crops that occur several times in a BatchNorm batch (one detection among the candidates of many tracks, zero
+        # padding) are computed once, with weighted batch statistics - same result up to summation order, less ReID work
+        self.dedup_crops = bool(getattr(args, "dedup_crops", True))
         self.expected_image_size = _ReIDFacade.PRETRAINED_SIZE
         self.reid_encoder = _ReIDFacade(self)
         self.attentions = None
@@ -233,7 +236,7 @@ class BUSCA:
         library).  Small batches are latency-bound, so this nearly halves their ReID time."""
         return self._reid_join(self._reid_side_start(can_u8), self._reid.forward(mem_u8))
 
-    def _reid_side_start(self, u8, zero_norm=None):
+    def _reid_side_start(self, u8, zero_norm=None, weights=None):
         """Enqueue one BatchNorm batch on the side stream (ordered after everything already on the current stream)."""
         dev = self._dev()
         cur = torch.cuda.current_stream(dev)
@@ -242,7 +245,7 @@ class BUSCA:
         side = self._side_stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            feat = self._reid.forward(u8, stream=side.cuda_stream, zero_norm=zero_norm)
+            feat = self._reid.forward(u8, stream=side.cuda_stream, zero_norm=zero_norm, weights=weights)
         u8.record_stream(side)
         if zero_norm is not None:
             zero_norm.record_stream(side)
@@ -343,7 +346,8 @@ class BUSCA:
 
         # the memory batch does not depend on the proposals: its ReID pass is enqueued NOW (side stream), so the host work
         # below (top-P selection, candidate lists) is hidden behind it
-        mem_feat_side = self._reid_side_start(*self._gather_crops(mem_ref, as_u8, zero_is_normalised))
+        mem_u8, mem_zn, mem_w, mem_inv = self._gather_crops(mem_ref, as_u8, zero_is_normalised)
+        mem_feat_side = self._reid_side_start(mem_u8, mem_zn, mem_w)
         gathered = self.last_gather
 
         # top-P nearest detections per track on the GPU (ascending centre distance, ties by lower index)
@@ -381,16 +385,21 @@ class BUSCA:
             mem_ltrb[..., 2:] += mem_ltrb[..., :2]
             can_ltrb[..., 2:] += can_ltrb[..., :2]
 
-        can_u8, can_zn = self._gather_crops(can_ref, as_u8, zero_is_normalised)
+        can_u8, can_zn, can_w, can_inv = self._gather_crops(can_ref, as_u8, zero_is_normalised)
         self.last_gather = (gathered[0] + self.last_gather[0], gathered[1] + self.last_gather[1])
-        can_feat = self._reid.forward(can_u8, zero_norm=can_zn)
+        can_feat = self._reid.forward(can_u8, zero_norm=can_zn, weights=can_w)
         return dict(B=B, N=N, K=K, P=P, L=L, order=order, n_avail=n_avail, reliable=reliable, mem_ltrb=mem_ltrb, can_ltrb=can_ltrb,
-                    mem_feat_side=mem_feat_side, can_feat=can_feat, select=bool(select_highest_candidate),
+                    mem_feat_side=mem_feat_side, can_feat=can_feat, mem_inv=mem_inv, can_inv=can_inv, select=bool(select_highest_candidate),
                     thresh=highest_candidate_minimum_thresh, keep=bool(keep_highest_value))
 
     def _assoc_features(self, job):
         """Join the side-stream ReID batch: (mem_feat [B,L,512], can_feat [B,P,512]), the two BN batches of network.py:192-193."""
         can_feat, mem_feat = self._reid_join(job["mem_feat_side"], job["can_feat"])
+        dev = mem_feat.device                  # features of the distinct crops -> the [B, L] / [B, P] slots they stand for
+        if len(job["mem_inv"]) != mem_feat.shape[0] or (job["mem_inv"] != np.arange(len(job["mem_inv"]))).any():
+            mem_feat = mem_feat[torch.from_numpy(job["mem_inv"]).to(dev)]
+        if len(job["can_inv"]) != can_feat.shape[0] or (job["can_inv"] != np.arange(len(job["can_inv"]))).any():
+            can_feat = can_feat[torch.from_numpy(job["can_inv"]).to(dev)]
         return mem_feat.view(job["B"], job["L"], -1), can_feat.view(job["B"], job["P"], -1)
 
     def _assoc_finish(self, job, out):
@@ -420,37 +429,56 @@ class BUSCA:
         return probs_matrix, job["reliable"]
 
     def _gather_crops(self, refs, as_u8, zero_is_normalised=False):
-        """[B][n] crop references (None = all-zero crop) -> (cuda u8 [B*n,384,128,3], zero flags | None) with ONE index-gather
-        launch (busca_gather_crops): crops that still own a slot of the device crop pool are read where they are; the rest
-        (plain arrays, spilled slots) go through one host batch first.  Replaces `_get_track_mem` + np.array stacking + H2D
-        of network.py:247-279,313-316,383-386."""
+        """[B][n] crop references (None = all-zero crop) -> (cuda u8 [U,384,128,3], zero flags | None, multiplicities [U] | None,
+        inverse [B*n]) with ONE index-gather launch (busca_gather_crops): crops that still own a slot of the device crop pool
+        are read where they are; the rest (plain arrays, spilled slots) go through one host batch first.  Replaces
+        `_get_track_mem` + np.array stacking + H2D of network.py:247-279,313-316,383-386.
+        Repeated crops (the same detection among the P nearest of several tracks, network.py:340-358; all zero crops) are
+        gathered ONCE: the extractor computes each distinct crop once and weights the batch statistics by its multiplicity."""
         dev = self._dev()
         flat = [r for row in refs for r in row]
-        ptrs = np.zeros(len(flat), np.uint64)
-        host_idx, host_arr = [], []
+        keys = np.zeros(len(flat), np.uint64)                # identity of every entry: pool address, or a host-object tag
+        host_first, host_objs = {}, []
         for i, r in enumerate(flat):
             if r is None:
                 continue
             slot = getattr(r, "slot", None)
             if slot is not None and slot.ptr and slot.pool.device == dev:
-                ptrs[i] = slot.ptr
+                keys[i] = slot.ptr
             else:
-                host_idx.append(i)
-                host_arr.append(as_u8(r))
+                tag = host_first.get(id(r))
+                if tag is None:
+                    tag = len(host_objs) + 1                 # small integers never collide with device addresses
+                    host_first[id(r)] = tag
+                    host_objs.append(r)
+                keys[i] = tag
+        if self.dedup_crops:
+            # distinct crops in order of FIRST APPEARANCE (np.unique sorts by key = address): the batch the extractor sees is
+            # then the same whether a crop came from the device pool or from the host, so both routes stay bit-identical
+            uniq, first, inverse, counts = np.unique(keys, return_index=True, return_inverse=True, return_counts=True)
+            order = np.argsort(first, kind="stable")
+            rank = np.empty_like(order)
+            rank[order] = np.arange(len(order))
+            uniq, counts, inverse = uniq[order], counts[order], rank[inverse]
+        else:
+            uniq, inverse, counts = keys, np.arange(len(keys)), np.ones(len(keys), np.int64)
+        ptrs = uniq.copy()
         staged = None
-        if host_idx:
-            staged = torch.from_numpy(np.stack(host_arr)).to(dev)
-            base = staged.data_ptr()
-            for k, i in enumerate(host_idx):
-                ptrs[i] = base + k * (384 * 128 * 3)
+        is_host = (uniq > 0) & (uniq <= len(host_objs))
+        if is_host.any():
+            staged = torch.from_numpy(np.stack([as_u8(host_objs[int(t) - 1]) for t in uniq[is_host]])).to(dev)
+            ptrs[is_host] = staged.data_ptr() + np.arange(int(is_host.sum()), dtype=np.uint64) * np.uint64(384 * 128 * 3)
         out = geometry.gather_crops(self._ctx, ptrs)
         if staged is not None:
             staged.record_stream(torch.cuda.current_stream(dev))
-        self.last_gather = (len(flat) - len(host_idx) - int((ptrs == 0).sum()), len(host_idx))   # (device-resident, host) crops
+        n_host = int(sum(counts[is_host])) if is_host.any() else 0
+        self.last_gather = (len(flat) - n_host - int((keys == 0).sum()), n_host)     # (device-resident, host) crops of the batch
+        self.last_unique = (len(uniq), len(flat))
         zn = None
-        if zero_is_normalised and (ptrs == 0).any():
-            zn = torch.from_numpy((ptrs == 0).astype(np.uint8)).to(dev)
-        return out, zn
+        if zero_is_normalised and (uniq == 0).any():
+            zn = torch.from_numpy((uniq == 0).astype(np.uint8)).to(dev)
+        wts = counts.astype(np.float32) if (counts > 1).any() else None
+        return out, zn, wts, inverse
 
     # ---- helpers with the reference's names ------------------------------------------------------------------
     def _get_track_mem(self, track, seq_len, use_broader_memory):

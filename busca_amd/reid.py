@@ -7,6 +7,10 @@ import torch
 from . import weights
 
 
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
 class ReIDEncoderHIP:
     """ResNet-50 (max pool, red=4) with batch-statistics BatchNorm, fp16 MFMA convs.
     `forward(crops_u8)`: u8 [n,384,128,3] BGR -> f32 [n,512] L2-normalised.  One call == one BN batch."""
@@ -32,8 +36,10 @@ class ReIDEncoderHIP:
         if owner is None or owner() is not self:
             self._upload()
 
-    def forward(self, crops_u8, stream=None, zero_norm=None):
-        """`zero_norm` (cuda u8 [n] or None): crops flagged 1 are 0.0 after normalisation (busca_reid_forward_ex)."""
+    def forward(self, crops_u8, stream=None, zero_norm=None, weights=None):
+        """`zero_norm` (cuda u8 [n] or None): crops flagged 1 are 0.0 after normalisation (busca_reid_forward_ex).
+        `weights` (numpy / sequence of n multiplicities, or None): crop i stands for weights[i] identical crops of the BatchNorm
+        batch - each distinct crop is computed once, the batch statistics count it weights[i] times (busca_reid_forward_w)."""
         self._ensure_loaded()
         dev = torch.device("cuda", self.ctx.device)
         if not torch.is_tensor(crops_u8):
@@ -44,5 +50,13 @@ class ReIDEncoderHIP:
         feats = torch.empty(n, 512, device=dev)
         s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         zn = zero_norm.data_ptr() if zero_norm is not None else None
-        self.ctx.check(self.ctx.lib.busca_reid_forward_ex(self.ctx.h, crops_u8.data_ptr(), n, zn, feats.data_ptr(), s))
+        wd, wsum = None, 0.0
+        if weights is not None:
+            w = np.ascontiguousarray(weights, dtype=np.float32)
+            assert w.shape == (n,) and (w >= 1).all()
+            wsum = float(w.astype(np.float64).sum())
+            wd = torch.from_numpy(w).to(dev)
+            if stream is not None:
+                wd.record_stream(torch.cuda.ExternalStream(stream, device=dev))
+        self.ctx.check(self.ctx.lib.busca_reid_forward_w(self.ctx.h, crops_u8.data_ptr(), n, zn, _ptr(wd), wsum, feats.data_ptr(), s))
         return feats

@@ -199,6 +199,14 @@ int busca_reid_forward(busca_ctx* ctx, const uint8_t* crops, int32_t n, float* f
  * associate_embeddings(normalize_ims=False) (busca/network.py:285,306,354: float32 zeros that skip _normalize_embeddings_batch);
  * its bytes in `crops` are ignored.  With normalize_ims=True the zero crops are u8 zeros and need no flag. */
 int busca_reid_forward_ex(busca_ctx* ctx, const uint8_t* crops, int32_t n, const uint8_t* zero_norm, float* feats, void* stream);
+/* The same BatchNorm batch with repeated crops given ONCE: weights dev f32 [n] = how often crop i occurs in the batch the
+ * reference builds (busca/network.py:340-358 picks each track's P nearest detections, so one detection's crop is repeated for
+ * many tracks: 4 096 candidate slots over ~160 detections at 128 lost x 32 proposals), weight_sum = their sum (host value).
+ * A crop's conv outputs do not depend on its copies; only the batch statistics do, and those are accumulated with the
+ * multiplicities - the result equals the forward over the expanded batch up to floating-point summation order.
+ * weights == NULL: every crop once (weight_sum ignored). */
+int busca_reid_forward_w(busca_ctx* ctx, const uint8_t* crops, int32_t n, const uint8_t* zero_norm, const float* weights, double weight_sum,
+                         float* feats, void* stream);
 /* Bytes of device workspace busca_reid_forward needs for n crops (allocated lazily inside the ctx). */
 size_t busca_reid_workspace_bytes(int32_t n);
 /*

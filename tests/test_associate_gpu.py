@@ -263,7 +263,12 @@ def test_crop_pool_is_bounded_over_a_long_sequence(model):
     dists = np.zeros((len(long_tracks), 1))
     a, ra = model.associate_embeddings(long_tracks, dets, dists, 11, 5, True, False, extra_kalman_candidates=long_tracks, normalize_ims=True)
     mixed = model.last_gather
-    plain = lambda trk: mg.FakeTrack(trk.tlwh_mem, [np.array(c) for c in trk.images_mem], trk.scale)
+    memo = {}                                 # one host copy per distinct crop object: repeated crops stay repeated objects,
+    def host(c):                              # which is what lets both routes give the extractor the same distinct-crop batch
+        if id(c) not in memo:
+            memo[id(c)] = np.array(c)
+        return memo[id(c)]
+    plain = lambda trk: mg.FakeTrack(trk.tlwh_mem, [host(c) for c in trk.images_mem], trk.scale)
     pl = [plain(t) for t in long_tracks]
     b, rb = model.associate_embeddings(pl, [plain(dets[0])], dists, 11, 5, True, False, extra_kalman_candidates=pl, normalize_ims=True)
     assert model.last_gather[0] == 0 and mixed[0] > 0
@@ -366,3 +371,21 @@ def test_step_batcher_is_bit_identical_to_per_sequence_calls(model, golden_dir):
     for (pm, rel), t in zip(singles, tickets):
         bpm, brel = t.result()
         assert np.array_equal(pm, bpm) and np.array_equal(rel, brel)
+
+
+def test_repeated_crops_are_computed_once(golden_dir):
+    """Candidate batches repeat crops (every track takes its P nearest detections; padding is all-zero crops): by default each
+    distinct crop is computed once with weighted BatchNorm statistics.  Exact flavours: same output as the expanded batch to
+    float32 round-off, and still on the reference's golden output."""
+    g = np.load(os.path.join(golden_dir, "assoc.npz"))
+    m = _model(64, 128, 17, "f32", "f32")
+    for ci in (0, 1, 2):
+        name, tracks, dets, kals, P = _case(ci)
+        m.dedup_crops = True
+        a, _ = m.associate_embeddings(tracks, dets, g[name + "_dists"], 11, P, True, False, extra_kalman_candidates=kals, normalize_ims=True)
+        uniq, slots = m.last_unique
+        m.dedup_crops = False
+        b, _ = m.associate_embeddings(tracks, dets, g[name + "_dists"], 11, P, True, False, extra_kalman_candidates=kals, normalize_ims=True)
+        assert m.last_unique[0] == m.last_unique[1] and uniq < slots          # the candidate batch really had repeats
+        assert np.abs(a - b).max() <= 5e-5, np.abs(a - b).max()
+        assert np.abs(a - g["%s_probs_f64_sel0" % name]).max() <= 2e-4

@@ -129,4 +129,8 @@ def test_cfg4_full_step_on_gpu_crops():
     ref = odt.dt_forward(a["_sd"], odt.DTConfig(d=512, ff=1024), mf, cf, inp["mem_boxes"], inp["can_boxes"], return_all=True)
     assert np.abs(a["_out"]["probs"] - ref["probs"].numpy()).max() <= 5e-3
     assert np.abs(a["_out"]["logits"] - ref["logits"].numpy()).max() <= 6e-2
-    assert a["crops_per_step"] == 128 * 43
+    assert a["crops_per_step"] == 128 * 43 and a["crops_computed"] <= 128 * 11 + 160
+    # the expanded candidate batch (4 096 crops, as the reference builds it) gives the same step up to summation order
+    e = cfg4_step.run(1, "f16", check=True, dedup=False)
+    assert (e["_feat"][1] * cf).sum(-1).min() >= 0.9998 and np.abs(e["_feat"][1] - cf).max() <= 5e-3
+    assert np.abs(e["_out"]["probs"] - a["_out"]["probs"]).max() <= 5e-3

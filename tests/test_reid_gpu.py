@@ -207,3 +207,50 @@ def test_reid_fused_tail_conv1_path(ctx, monkeypatch):
     monkeypatch.delenv("BUSCA_REID_FUSE_C1")
     monkeypatch.delenv("BUSCA_REID_GRAM")
     ReIDEncoderHIP(ctx, sd)
+
+
+@pytest.mark.parametrize("prec", ["f16", "f32"])
+def test_reid_weighted_statistics_equal_the_expanded_batch(ctx, prec):
+    """busca_reid_forward_w: a BatchNorm batch in which crops repeat (the same detection among the candidates of several tracks,
+    zero padding) given as distinct crops + multiplicities equals the forward over the expanded batch - up to floating-point
+    summation order of the statistics - and stays on the oracle evaluated on the expanded batch."""
+    from busca_amd.reid import ReIDEncoderHIP
+    from oracle import reid as oreid
+    sd = synth.reid_state_dict(3)
+    uniq = _crops(777, 7)
+    uniq[3] = 0                                                   # a zero (padding) crop among them
+    counts = np.array([5, 1, 2, 9, 1, 3, 1])
+    inverse = np.repeat(np.arange(7), counts)
+    rng = np.random.default_rng(0)
+    rng.shuffle(inverse)
+    expanded = uniq[inverse]                                      # 22 crops, 7 distinct
+    m = ReIDEncoderHIP(ctx, sd, precision=prec)
+    full = m.forward(expanded).cpu().numpy()
+    w = m.forward(uniq, weights=counts).cpu().numpy()[inverse]
+    assert np.array_equal(m.forward(uniq, weights=counts).cpu().numpy()[inverse], w)            # deterministic
+    if prec == "f32":
+        assert np.abs(w - full).max() <= 2e-5, np.abs(w - full).max()
+    else:     # one flipped fp16 rounding early in the network moves the features by ~2e-3 (as between the other schedules)
+        assert np.abs(w - full).max() <= 5e-3 and (w * full).sum(1).min() >= 0.9998
+    ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(expanded)).numpy()
+    if prec == "f32":
+        assert np.abs(w - ref).max() <= 5e-5
+    else:
+        assert (w * ref).sum(1).min() >= COS_MIN and np.abs(w - ref).max() <= FEAT_ATOL
+    # weights of all ones are the plain forward, bit for bit
+    assert np.array_equal(m.forward(uniq, weights=np.ones(7)).cpu().numpy(), m.forward(uniq).cpu().numpy())
+
+
+def test_reid_weighted_statistics_large_duplication(ctx):
+    """MOT20-like candidate batch: 1 024 slots drawn from 48 detections (every layer's tile / crop alignment is exercised:
+    48 crops put layer 3 at 9 216 pixels, layer 4 at 2 304) against the expanded batch."""
+    from busca_amd.reid import ReIDEncoderHIP
+    sd = synth.reid_state_dict(3)
+    uniq = _crops(4242, 48)
+    inverse = np.random.default_rng(1).integers(0, 48, 1024)
+    inverse[:48] = np.arange(48)
+    counts = np.bincount(inverse, minlength=48)
+    m = ReIDEncoderHIP(ctx, sd)
+    full = m.forward(uniq[inverse]).cpu().numpy()
+    w = m.forward(uniq, weights=counts).cpu().numpy()[inverse]
+    assert np.abs(w - full).max() <= 5e-3 and (w * full).sum(1).min() >= 0.9998

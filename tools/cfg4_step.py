@@ -4,7 +4,10 @@
 One full step = crop gather of the frame's detections (busca_crop_gather) -> index gather of the two crop batches
 (busca_gather_crops: 128 x 11 memory crops from the device pool, 128 x 32 candidate crops out of the frame's detections) ->
 ReID over the two BatchNorm batches (1 408 and 4 096 crops, two streams) -> Decision Transformer (T = 79 tokens per track,
-layer-wise path) -> probabilities.  python tools/cfg4_step.py [steps] [dt_precision]"""
+layer-wise path) -> probabilities.  The 4 096 candidate slots are filled from the frame's ~160 detections (every track takes
+its 32 nearest): with dedup (default, what BUSCA.associate_embeddings does) the extractor computes each distinct detection crop
+once and weights the BatchNorm statistics by its multiplicity (busca_reid_forward_w); dedup=False runs the expanded batch
+exactly as the reference builds it.  python tools/cfg4_step.py [steps] [dt_precision] [nodedup]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,7 +19,7 @@ from busca_amd.reid import ReIDEncoderHIP
 REID_GFLOP_PER_CROP = 8.01
 
 
-def run(steps=3, precision="f16", B=128, L=11, P=32, n_det=160, d=512, check=False, seed=7):
+def run(steps=3, precision="f16", B=128, L=11, P=32, n_det=160, d=512, check=False, seed=7, dedup=True):
     dev = torch.device("cuda", 0)
     ctx = _lib.Context(0)
     reid = ReIDEncoderHIP(ctx, synth.reid_state_dict(seed))
@@ -43,15 +46,22 @@ def run(steps=3, precision="f16", B=128, L=11, P=32, n_det=160, d=512, check=Fal
     def one():
         det_u8, _ = geometry.crop_gather(ctx, frame, det_tlbr, want_u8=True)          # this frame's detections, cut on the GPU
         base = det_u8.data_ptr()
-        can_ptrs = (base + order.reshape(-1).astype(np.uint64) * np.uint64(384 * 128 * 3)).astype(np.uint64)
         mem_u8 = geometry.gather_crops(ctx, mem_ptrs)
-        can_u8 = geometry.gather_crops(ctx, can_ptrs)
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             mf = reid.forward(mem_u8, stream=side.cuda_stream).view(B, L, -1)
         mem_u8.record_stream(side)
-        cf = reid.forward(can_u8).view(B, P, -1)
+        flat = order.reshape(-1)
+        if dedup:                                  # distinct detections in order of first appearance + multiplicities
+            uniq, first, inverse, counts = np.unique(flat, return_index=True, return_inverse=True, return_counts=True)
+            o = np.argsort(first, kind="stable"); rank = np.empty_like(o); rank[o] = np.arange(len(o))
+            uniq, counts, inverse = uniq[o], counts[o], rank[inverse]
+            can_u8 = geometry.gather_crops(ctx, (base + uniq.astype(np.uint64) * np.uint64(384 * 128 * 3)).astype(np.uint64))
+            cf = reid.forward(can_u8, weights=counts)[torch.from_numpy(inverse).to(dev)].view(B, P, -1)
+        else:
+            can_u8 = geometry.gather_crops(ctx, (base + flat.astype(np.uint64) * np.uint64(384 * 128 * 3)).astype(np.uint64))
+            cf = reid.forward(can_u8).view(B, P, -1)
         cur.wait_stream(side)
         out = dt.forward(mf, cf, mb, cb)
         return out, mf, cf
@@ -64,9 +74,11 @@ def run(steps=3, precision="f16", B=128, L=11, P=32, n_det=160, d=512, check=Fal
     torch.cuda.synchronize(dev)
     el = (time.perf_counter() - t0) / steps
     crops = B * (L + P)
-    res = {"workload": "cfg4 full step: %d lost x %d proposals x d%d, %d + %d crops cut/gathered on the GPU, ReID (fp16) + DT (%s)" % (B, P, d, B * L, B * P, precision),
-           "value": 1.0 / el, "unit": "steps/s", "ms_per_step": el * 1e3, "crops_per_step": crops, "steps": steps,
-           "reid_tflops": crops * REID_GFLOP_PER_CROP / el / 1e3, "frac_of_f16_mfma_peak": crops * REID_GFLOP_PER_CROP / el / 1e3 / 2500.0}
+    computed = B * L + (len(np.unique(order)) if dedup else B * P)
+    res = {"workload": "cfg4 full step: %d lost x %d proposals x d%d, %d + %d crop slots cut/gathered on the GPU (%d detections), ReID (fp16) + DT (%s)%s"
+                       % (B, P, d, B * L, B * P, n_det, precision, "; repeated candidate crops computed once, statistics weighted" if dedup else "; expanded candidate batch"),
+           "value": 1.0 / el, "unit": "steps/s", "ms_per_step": el * 1e3, "crops_per_step": crops, "crops_computed": computed, "steps": steps,
+           "reid_tflops_executed": computed * REID_GFLOP_PER_CROP / el / 1e3, "frac_of_f16_mfma_peak_executed": computed * REID_GFLOP_PER_CROP / el / 1e3 / 2500.0}
     if check:
         res["_out"] = {k: v.cpu().numpy() for k, v in out.items()}
         res["_feat"] = (mf.cpu().numpy(), cf.cpu().numpy())
@@ -77,5 +89,5 @@ def run(steps=3, precision="f16", B=128, L=11, P=32, n_det=160, d=512, check=Fal
 
 
 if __name__ == "__main__":
-    r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 3, sys.argv[2] if len(sys.argv) > 2 else "f16")
+    r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 3, sys.argv[2] if len(sys.argv) > 2 else "f16", dedup="nodedup" not in sys.argv)
     print({k: v for k, v in r.items() if not k.startswith("_")})
