@@ -267,8 +267,11 @@ def assoc_e2e(frames):
         r = e2e_sim.run(lost, objs, 5, 512, "f16", frames, verbose=False)
         out["lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "p50_center_distance_ms",
                                                                           "busca_frames_per_s", "device_resident_crops")}
+    import gc
+    gc.collect(); torch.cuda.empty_cache()      # the previous scenes' models / crop pools go away before the next one is timed
     r = e2e_sim.run(8, 60, 5, 512, "f16", frames, verbose=False, device_only_crops=True)     # opt-in: crops never copied back to the host
     out["lost8_dets52_device_only_crops"] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "busca_frames_per_s")}
+    gc.collect(); torch.cuda.empty_cache()
     try:        # several trackers on one GPU: the steps of one frame interval through the StepBatcher (one DT launch)
         out["multi_sequence_4x_lost8"] = e2e_sim.run_multi(4, 8, 60, 5, 512, "f16", frames)
     except Exception as e:
