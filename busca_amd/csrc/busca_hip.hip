@@ -343,14 +343,30 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
 }
 
 // ---- tiled (layer-wise) path ---------------------------------------------------------------------------------------
-template <int PREC, int D, int EPI>
-static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblocks) {
-    const size_t lds = (size_t)(DTL_BM + D) * 128 + 2 * 4 * DTL_BM * sizeof(float);
-    auto kern = dtl_gemm_kernel<PREC, D, EPI>;
+template <int PREC, int D, int EPI, int RT>
+static int dtl_gemm_rt(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblocks) {
+    constexpr int BM = 32 * RT;
+    const size_t lds = (size_t)(BM + D) * 128 + 2 * 4 * BM * sizeof(float);
+    auto kern = dtl_gemm_kernel<PREC, D, EPI, RT>;
     { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
     TimedLaunch tl(c, s);
-    hipLaunchKernelGGL(kern, dim3((a.M + DTL_BM - 1) / DTL_BM, ncolblocks), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((a.M + BM - 1) / BM, ncolblocks), dim3(512), lds, s, a);
     return BUSCA_OK;
+}
+
+// 64-row tiles (two workgroups per CU: one's epilogue traffic overlaps the other's MFMA phase) for the epilogue-heavy GEMMs
+// when the tile fits twice into the LDS (d <= 512); BUSCA_DTL_RT=4 / 2 forces either geometry.
+template <int PREC, int D, int EPI>
+static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblocks) {
+    static const int rt_env = getenv("BUSCA_DTL_RT") ? atoi(getenv("BUSCA_DTL_RT")) : 0;
+    static const int rt_mask = getenv("BUSCA_DTL_RT_MASK") ? atoi(getenv("BUSCA_DTL_RT_MASK")) : -1;     // bit EPI = 64-row tiles for that GEMM
+    // default: 64-row tiles only when 128-row tiles would not fill the chip once (fewer than 256 workgroups) - measured
+    // 128 lost x 32 proposals x d512: f32 3.38 -> 2.86 ms, f16 0.93 -> 0.89 ms; at >= 256 workgroups the two geometries are within
+    // +-8 % per GEMM kind with no consistent winner (512 x 64 x d512: 4.25 ms with 128 rows, 4.6 ms with 64)
+    const bool underfilled = (long)((a.M + 127) / 128) * ncolblocks < 256;
+    const bool small = rt_mask >= 0 ? ((rt_mask >> EPI) & 1) != 0 : (rt_env == 2 || (rt_env == 0 && underfilled));
+    if (small && (size_t)(64 + D) * 128 + 2 * 4 * 64 * 4 <= 80 * 1024) return dtl_gemm_rt<PREC, D, EPI, 2>(c, s, a, ncolblocks);
+    return dtl_gemm_rt<PREC, D, EPI, 4>(c, s, a, ncolblocks);
 }
 
 template <int PREC, int D, int MT>
