@@ -140,3 +140,46 @@ def test_blob_round_trip_and_decision_rule():
     matches, unmatched = recover_with_busca(probs, np.array([True, True, False]), 5, 0.5)
     assert matches == [[0, 0.9]] and unmatched == [1, 2]
     assert recover_with_busca(None, None, 5, 0.5) == ([], [])
+
+
+def test_checkpoint_loading_is_strict_like_the_reference(tmp_path):
+    """`model_dict.update(ckpt); load_state_dict(model_dict)` (network.py:465-467, load_trained_net.py:64-66) raises on keys the
+    model does not have; here too - a wrong checkpoint must not leave the tracker on its seeded synthetic weights silently."""
+    import warnings
+    import numpy as np, pytest, torch
+    from busca_amd import synth
+    from busca_amd.network import BUSCA
+    sd = {k: torch.from_numpy(v) for k, v in synth.dt_state_dict(99, d=64, ff=128).items()}
+    sd.update({"reid_encoder.model." + k: torch.from_numpy(v) for k, v in synth.reid_state_dict(99).items()})
+    # DDP-style prefix: every key is foreign -> raise
+    p = tmp_path / "ddp.pth"
+    torch.save({"module." + k: v for k, v in sd.items()}, p)
+    with pytest.raises(RuntimeError, match="unexpected key"):
+        BUSCA(_args()).load_pretrained(str(p))
+    # a different flavour (an extra learned token) -> raise
+    p = tmp_path / "flavour.pth"
+    torch.save(dict(sd, extra_token=torch.zeros(64)), p)
+    with pytest.raises(RuntimeError, match="extra_token"):
+        BUSCA(_args()).load_pretrained(str(p))
+    # a checkpoint that lacks parameters keeps the current values but says so
+    p = tmp_path / "partial.pth"
+    torch.save({k: v for k, v in sd.items() if not k.startswith("decoder.")}, p)
+    m = BUSCA(_args())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.load_pretrained(str(p))
+    assert any("decoder" in str(x.message) for x in w)
+    assert np.array_equal(m._sd["encoder.weight"], sd["encoder.weight"].numpy())
+    # ReID weights file (load_net): the same strictness, fc heads dropped as the reference does
+    p = tmp_path / "reid.pth"
+    rsd = {k: torch.from_numpy(v) for k, v in synth.reid_state_dict(5, with_fc=True).items()}
+    torch.save(rsd, p)
+    a = _args(); a.reid_weights_file = str(p)
+    m = BUSCA(a)
+    assert np.array_equal(m._sd["reid_encoder.model.layer1.0.conv1.weight"], rsd["layer1.0.conv1.weight"].numpy())
+    torch.save(dict(rsd, **{"backbone.conv9.weight": torch.zeros(3)}), p)
+    with pytest.raises(RuntimeError, match="unexpected key"):
+        BUSCA(a)
+    # strict load_state_dict: missing keys raise
+    with pytest.raises(RuntimeError, match="missing"):
+        BUSCA(_args()).load_state_dict({"encoder.weight": sd["encoder.weight"]})

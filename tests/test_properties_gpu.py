@@ -134,3 +134,43 @@ def test_cfg4_full_step_on_gpu_crops():
     e = cfg4_step.run(1, "f16", check=True, dedup=False)
     assert (e["_feat"][1] * cf).sum(-1).min() >= 0.9998 and np.abs(e["_feat"][1] - cf).max() <= 5e-3
     assert np.abs(e["_out"]["probs"] - a["_out"]["probs"]).max() <= 5e-3
+
+
+def test_new_entry_points_empty_and_error_paths(ctx):
+    """Round-2 C-ABI entries: empty inputs are no-ops, bad arguments are refused with a message (never a crash or a silent pass)."""
+    import ctypes as C
+    from busca_amd import _lib
+    lib, h = ctx.lib, ctx.h
+    out = torch.zeros(2, 384, 128, 3, dtype=torch.uint8, device="cuda")
+    assert lib.busca_gather_crops(h, None, 0, None, None) == 0
+    assert lib.busca_gather_crops(h, None, 2, out.data_ptr(), None) == -1 and b"null" in lib.busca_last_error(h)
+    assert lib.busca_gather_crops(h, out.data_ptr(), -1, out.data_ptr(), None) == -1
+    zero_src = torch.zeros(2, dtype=torch.int64, device="cuda")                      # address 0 = zero crop
+    out.fill_(7)
+    assert lib.busca_gather_crops(h, zero_src.data_ptr(), 2, out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int(out.max()) == 0
+    frame = torch.zeros(64, 64, 3, dtype=torch.uint8, device="cuda")
+    rects = torch.zeros(1, 4, dtype=torch.int32, device="cuda")
+    assert lib.busca_crop_gather_ex(h, frame.data_ptr(), 64, 64, 192, rects.data_ptr(), 0, None, None, None, None) == 0
+    assert lib.busca_crop_gather_ex(h, frame.data_ptr(), 64, 64, 192, rects.data_ptr(), 1, None, None, None, None) == -1
+    assert lib.busca_crop_gather_ex(h, frame.data_ptr(), 64, 64, 10, rects.data_ptr(), 1, None, out.data_ptr(), None, None) == -1
+    c2 = _lib.Context(0)
+    feats = torch.zeros(2, 512, device="cuda")
+    assert c2.lib.busca_reid_forward_w(c2.h, out.data_ptr(), 2, None, None, 0.0, feats.data_ptr(), None) == -2           # no weights loaded
+    assert c2.lib.busca_dt_reserve(c2.h, 4, 11, 5, None) == -2
+    warp = np.eye(2, 3, dtype=np.float32)
+    cc = C.c_double(0)
+    assert c2.lib.busca_ecc_align(c2.h, None, frame.data_ptr(), 64, 64, 192, 192, 0, 10, 1e-5, warp.ctypes.data, C.byref(cc), None, None) == -1
+    assert c2.lib.busca_ecc_align(c2.h, frame.data_ptr(), frame.data_ptr(), 64, 64, 192, 192, 2, 10, 1e-5, warp.ctypes.data, C.byref(cc), None, None) == -1
+    # a constant image pair has no gradient: OpenCV raises, the kernel path returns an error code with a message
+    assert c2.lib.busca_ecc_align(c2.h, frame.data_ptr(), frame.data_ptr(), 64, 64, 192, 192, 0, 10, 1e-5, warp.ctypes.data, C.byref(cc), None, None) == -1
+    assert len(c2.lib.busca_last_error(c2.h)) > 0
+    c2.close()
+    # weighted forward: weight_sum must be given with the weights
+    from busca_amd.reid import ReIDEncoderHIP
+    m = ReIDEncoderHIP(ctx, synth.reid_state_dict(3))
+    w = torch.ones(2, device="cuda")
+    assert lib.busca_reid_forward_w(h, out.data_ptr(), 2, None, w.data_ptr(), 0.0, feats.data_ptr(), None) == -1
+    assert lib.busca_reid_forward_w(h, out.data_ptr(), 0, None, None, 0.0, feats.data_ptr(), None) == 0
+    del m
