@@ -1,7 +1,7 @@
 # rocprofv3 evidence for the round: kernel-trace stats of the default bench legs + ReID passes, PMC of the DT kernels
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r2g; mkdir -p $O
+O=gpurun_out/prof; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dt_f32 -o t -- python3 bench.py --precision f32 --steps 160 --warmup 16 --cpu-seconds 0 --latency-samples 0 --no-variants > $O/dt_f32.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dt_f16 -o t -- python3 bench.py --precision f16 --inflight 16 --steps 320 --warmup 32 --cpu-seconds 0 --latency-samples 0 --no-variants > $O/dt_f16.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/reid512 -o t -- python3 tools/reid_bench.py 512 3 > $O/reid512.log 2>&1
