@@ -305,19 +305,29 @@ def main():
     if world != args.gpus and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     dist = None
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  BUSCA_BENCH_BACKEND=gloo is a TEST mode for boxes with fewer GPUs than ranks: ranks wrap around the
+    # visible devices and the bookkeeping (barrier, max over ranks, rank reports) runs over gloo instead of RCCL, so the N > 1
+    # code path can be exercised on a 1-GPU box; its numbers mean nothing.
+    backend = os.environ.get("BUSCA_BENCH_BACKEND", "nccl")
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from busca_amd import _lib, sharding
 
     B, P, L, d, ff, F = args.lost, args.proposals, args.seq_len, args.d, 2 * args.d, max(1, args.inflight)
     seed = 7   # the reference configs' tracker.seed (config/*/*/*.yml:18)
     sd = synth.dt_state_dict(seed, d=d, ff=ff)
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(dev_index)
     # synthetic inputs resident in HBM before the timed region: F steps worth of tracks, each rank its own seed
     big = synth.dt_inputs(seed + 1000 * rank, B * F, L, P)
     tens = {k: torch.from_numpy(v).to(dev) for k, v in big.items()}
@@ -340,7 +350,7 @@ def main():
     elapsed = time.perf_counter() - t0
     my_elapsed = elapsed
     ev_ms = ev0.elapsed_time(ev1)
-    elapsed = sharding.max_over_ranks(elapsed, dist, dev)
+    elapsed = sharding.max_over_ranks(elapsed, dist, red_dev)
     # who was live: every rank reports (rank, device index, device name, library version, its own elapsed time)
     me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev),
           "busca_version": int(ctx.lib.busca_version()), "elapsed_s": my_elapsed, "steps": args.steps}
@@ -367,7 +377,8 @@ def main():
             "config": {"workload": "cfgN DT-step: %d lost x %d proposals x d%d (L=%d, T=%d, ff=%d, 4 layers, 4 heads), ReID features "
                                    "precomputed; BASELINE.json configs[1]-shaped batch without the tracker" % (B, P, d, L, L + 2 * (P + 2), ff),
                        "lost": B, "proposals": P, "d": d, "seq_len": L, "steps_in_flight_per_launch": F,
-                       "parallelism": "independent sequences sharded per GPU, no collective (%d rank%s)" % (world, "" if world == 1 else "s")},
+                       "parallelism": "independent sequences sharded per GPU, no collective (%d rank%s)%s" % (
+                           world, "" if world == 1 else "s", "" if backend == "nccl" else "; TEST MODE backend=%s, ranks share %d GPU(s)" % (backend, ndev))},
             "roofline": roofline_obj(args.precision, B, L, P, d, ff, timing, ev_ms / max(1, n_launch)),
             "ranks": ranks,
         }
