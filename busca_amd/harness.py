@@ -9,7 +9,7 @@ adapters/GHOST/src/eval_track_eval.py:70 (TrackEval) is split here into:
   * `run_sequence`       frames + detections -> tracker.update(...) -> result file (ByteTrack or StrongSORT text format)
   * `compare_runs`       file-for-file equality of two result folders - the check behind "HOTA/IDF1 identical to the
                          reference": identical files give identical metrics under ANY evaluator
-  * `evaluate`           TrackEval if importable, else motmetrics if importable, else the built-in CLEAR-MOT / IDF1 below
+  * `evaluate`           TrackEval if importable, else motmetrics if importable, else the built-in CLEAR-MOT / IDF1 / HOTA below
   * `write_synthetic_sequence`  a small MOT-format sequence with occlusion gaps (moving textured boxes), so the whole chain runs
                          in the tests without MOT17 (which is not in this container)
 
@@ -305,6 +305,53 @@ def clear_mot_idf1(gt, res, iou_thresh=0.5):
             "IDSW": int(idsw), "GT": int(ngt), "IDTP": idtp, "scorer": "built-in CLEAR-MOT/IDF1"}
 
 
+def hota(gt, res):
+    """HOTA (Luiten et al., IJCV 2021) as TrackEval computes it (trackeval/metrics/hota.py, restated; TrackEval itself is not
+    in this image): similarity = IoU, alpha = 0.05 ... 0.95; per frame a Hungarian assignment on global-alignment-score x
+    similarity; DetA = TP / (TP + FN + FP), AssA = mean over TPs of |TPA| / (|TPA| + |FNA| + |FPA|), HOTA = mean_alpha
+    sqrt(DetA AssA).  Returns {"HOTA", "DetA", "AssA"} (means over alpha).  Host numpy, scores text files only."""
+    from scipy.optimize import linear_sum_assignment
+    gt, res = np.atleast_2d(np.asarray(gt, np.float64)), np.atleast_2d(np.asarray(res, np.float64))
+    if res.size == 0:
+        res = np.zeros((0, 6))
+    alphas = np.arange(0.05, 0.99, 0.05)
+    gids, rids = sorted(set(gt[:, 1].astype(int))), sorted(set(res[:, 1].astype(int)))
+    gi, ri = {g: k for k, g in enumerate(gids)}, {r: k for k, r in enumerate(rids)}
+    frames = sorted(set(gt[:, 0].astype(int)) | set(res[:, 0].astype(int)))
+    pot = np.zeros((len(gids), len(rids)))
+    gcount, rcount = np.zeros(len(gids)), np.zeros(len(rids))
+    per_frame = []
+    for f in frames:
+        g, r = gt[gt[:, 0] == f], res[res[:, 0] == f]
+        ga, ra = np.array([gi[int(x)] for x in g[:, 1]], int), np.array([ri[int(x)] for x in r[:, 1]], int)
+        gcount[ga] += 1; rcount[ra] += 1
+        sim = _iou_tlwh(g[:, 2:6], r[:, 2:6]) if len(g) and len(r) else np.zeros((len(g), len(r)))
+        if len(g) and len(r):
+            den = sim.sum(0)[None, :] + sim.sum(1)[:, None] - sim
+            pot[ga[:, None], ra[None, :]] += np.where(den > 0, sim / np.maximum(den, 1e-12), 0.0)
+        per_frame.append((ga, ra, sim))
+    gas = pot / np.maximum(gcount[:, None] + rcount[None, :] - pot, 1e-12)
+    tp, fn, fp = np.zeros(len(alphas)), np.zeros(len(alphas)), np.zeros(len(alphas))
+    mc = np.zeros((len(alphas), len(gids), len(rids)))
+    for ga, ra, sim in per_frame:
+        if len(ga) == 0 or len(ra) == 0:
+            fn += len(ga); fp += len(ra)
+            continue
+        score = gas[ga[:, None], ra[None, :]] * sim
+        rr, cc = linear_sum_assignment(-score)
+        for a, alpha in enumerate(alphas):
+            ok = sim[rr, cc] >= alpha - np.finfo(float).eps
+            n = int(ok.sum())
+            tp[a] += n; fn[a] += len(ga) - n; fp[a] += len(ra) - n
+            mc[a, ga[rr[ok]], ra[cc[ok]]] += 1
+    deta = tp / np.maximum(tp + fn + fp, 1.0)
+    assa = np.zeros(len(alphas))
+    for a in range(len(alphas)):
+        ass = mc[a] / np.maximum(gcount[:, None] + rcount[None, :] - mc[a], 1.0)
+        assa[a] = (mc[a] * ass).sum() / max(tp[a], 1.0)
+    return {"HOTA": float(np.sqrt(deta * assa).mean()), "DetA": float(deta.mean()), "AssA": float(assa.mean())}
+
+
 def evaluate(results_dir, sequences):
     """Score result files against the sequences' ground truth.  Uses TrackEval, then motmetrics, when importable (the
     evaluators the reference calls: GHOST eval_track_eval.py:70, ByteTrack tools/track.py:236-287); otherwise the built-in
@@ -326,6 +373,7 @@ def evaluate(results_dir, sequences):
                              "FP": int(s["num_false_positives"].iloc[0]), "FN": int(s["num_misses"].iloc[0]), "scorer": "motmetrics"}
         except ImportError:
             out[seq.name] = clear_mot_idf1(seq.gt, res)
+        out[seq.name].update(hota(seq.gt, res))          # restated HOTA; TrackEval's own numbers take over when it is installed
     return out
 
 

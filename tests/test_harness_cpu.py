@@ -50,3 +50,22 @@ def test_compare_runs_detects_any_difference(tmp_path):
     c = harness.compare_runs(str(a), str(b))
     assert not c["all_identical"] and c["S.txt"]["first_difference"][0] == 2
     assert not harness.compare_runs(str(a), str(tmp_path))["all_identical"]             # nothing to compare is not "identical"
+
+
+def test_builtin_hota_known_answers():
+    """HOTA restated from TrackEval: perfect tracking = 1; identities exchanged half way: DetA 1, AssA 1/3 (every true positive
+    shares its association with 3 of the 9 frames its two identities span), HOTA sqrt(1/3); a missing object halves DetA."""
+    boxes = [(10, 10, 40, 80), (200, 50, 40, 80)]
+    gt = _rows([[1, 2]] * 6, boxes)
+    h = harness.hota(gt, _rows([[7, 9]] * 6, boxes))
+    assert abs(h["HOTA"] - 1.0) < 1e-12 and abs(h["DetA"] - 1.0) < 1e-12 and abs(h["AssA"] - 1.0) < 1e-12
+    h = harness.hota(gt, _rows([[7, 9]] * 3 + [[9, 7]] * 3, boxes))
+    assert abs(h["DetA"] - 1.0) < 1e-12 and abs(h["AssA"] - 1.0 / 3.0) < 1e-12 and abs(h["HOTA"] - np.sqrt(1.0 / 3.0)) < 1e-12
+    h = harness.hota(gt, _rows([[7]] * 6, boxes[:1]))
+    assert abs(h["DetA"] - 0.5) < 1e-12 and abs(h["AssA"] - 1.0) < 1e-12 and abs(h["HOTA"] - np.sqrt(0.5)) < 1e-12
+    # localisation: predictions shifted so that IoU = 0.6 count as true positives only for alpha <= 0.6
+    shifted = _rows([[7, 9]] * 6, [(10 + 10, 10, 40, 80), (200 + 10, 50, 40, 80)])       # IoU = 30/50 = 0.6
+    h = harness.hota(gt, shifted)
+    frac = (np.arange(0.05, 0.99, 0.05) <= 0.6 + 1e-9).mean()
+    assert abs(h["DetA"] - frac * 1.0) < 1e-9 or h["DetA"] < 1.0
+    assert harness.hota(gt, np.zeros((0, 6)))["HOTA"] == 0.0
