@@ -217,7 +217,8 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None):
     boxes = synth.dt_inputs(7, B, L, P)
     mb, cb = torch.from_numpy(boxes["mem_boxes"]).to(dev), torch.from_numpy(boxes["can_boxes"]).to(dev)
 
-    side = torch.cuda.Stream(dev)
+    from busca_amd.network import _side_stream_of
+    side = _side_stream_of(dev)               # the process-wide side stream (see busca_amd/network.py)
 
     def one():                                           # as BUSCA._reid_pair: the two BN batches run on two streams
         cur = torch.cuda.current_stream(dev)

@@ -22,6 +22,16 @@ _PIX_MEAN_RGB = np.array([0.485, 0.456, 0.406], dtype=np.float64)
 _PIX_STD_RGB = np.array([0.299, 0.224, 0.225], dtype=np.float64)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream_of(dev):
+    key = dev.index or 0
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
+    return _SIDE_STREAMS[key]
+
+
 def memory_indices(n_hist, seq_len, use_broader_memory):
     """Which history entries form a track's memory (busca/network.py:247-275): the last `seq_len`, or - with
     `use_broader_memory` and a long enough history - `seq_len` entries spread evenly from first to last."""
@@ -241,7 +251,11 @@ class BUSCA:
         dev = self._dev()
         cur = torch.cuda.current_stream(dev)
         if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream(dev)
+            # ONE side stream per device and process, shared by every model: HIP deals streams to its few hardware queues
+            # round-robin, and a side stream that lands on the queue of the current stream serialises the two ReID passes of a
+            # step (4.4 -> 5.9 ms; seen on about one model instance in four when every instance made its own stream - a
+            # high-priority stream was worse, 7.8 ms).  The first stream a process creates sits next to the default queue.
+            self._side_stream = _side_stream_of(dev)
         side = self._side_stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):

@@ -51,6 +51,8 @@ class ReIDEncoderHIP:
         s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         zn = zero_norm.data_ptr() if zero_norm is not None else None
         wd, wsum = None, 0.0
+        if weights is not None and not (np.asarray(weights) != 1).any():
+            weights = None                      # every crop once: the plain forward (same schedule, bit for bit)
         if weights is not None:
             w = np.ascontiguousarray(weights, dtype=np.float32)
             assert w.shape == (n,) and (w >= 1).all()

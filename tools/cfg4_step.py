@@ -41,7 +41,8 @@ def run(steps=3, precision="f16", B=128, L=11, P=32, n_det=160, d=512, check=Fal
     order = np.stack([rng.permutation(n_det)[:P] for _ in range(B)])                 # each track's P nearest detections
     inp = synth.dt_inputs(seed, B, L, P)
     mb, cb = torch.from_numpy(inp["mem_boxes"]).to(dev), torch.from_numpy(inp["can_boxes"]).to(dev)
-    side = torch.cuda.Stream(dev)
+    from busca_amd.network import _side_stream_of
+    side = _side_stream_of(dev)               # the process-wide side stream (see busca_amd/network.py)
 
     def one():
         det_u8, _ = geometry.crop_gather(ctx, frame, det_tlbr, want_u8=True)          # this frame's detections, cut on the GPU
