@@ -360,10 +360,11 @@ template <int PREC, int D, int EPI>
 static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblocks) {
     static const int rt_env = getenv("BUSCA_DTL_RT") ? atoi(getenv("BUSCA_DTL_RT")) : 0;
     static const int rt_mask = getenv("BUSCA_DTL_RT_MASK") ? atoi(getenv("BUSCA_DTL_RT_MASK")) : -1;     // bit EPI = 64-row tiles for that GEMM
-    // default: 64-row tiles only when 128-row tiles would not fill the chip once (fewer than 256 workgroups) - measured
-    // 128 lost x 32 proposals x d512: f32 3.38 -> 2.86 ms, f16 0.93 -> 0.89 ms; at >= 256 workgroups the two geometries are within
-    // +-8 % per GEMM kind with no consistent winner (512 x 64 x d512: 4.25 ms with 128 rows, 4.6 ms with 64)
-    const bool underfilled = (long)((a.M + 127) / 128) * ncolblocks < 256;
+    // default: 64-row tiles only when 128-row tiles would fill less than half the chip (fewer than 128 workgroups) - measured
+    // 128 lost x 32 proposals x d512 (79 row blocks): 64-row tiles for the single-column-block GEMMs 0.93 -> 0.86 ms (f16), f32
+    // 3.38 -> 2.9 ms; from 158 row blocks on (two such steps in flight) 64-row tiles LOSE 5-10 %, and at >= 256 workgroups
+    // the two geometries are within +-8 % per GEMM kind with no consistent winner (512 x 64 x d512: 4.25 ms vs 4.6 ms)
+    const bool underfilled = (long)((a.M + 127) / 128) * ncolblocks < 128;
     const bool small = rt_mask >= 0 ? ((rt_mask >> EPI) & 1) != 0 : (rt_env == 2 || (rt_env == 0 && underfilled));
     if (small && (size_t)(64 + D) * 128 + 2 * 4 * 64 * 4 <= 80 * 1024) return dtl_gemm_rt<PREC, D, EPI, 2>(c, s, a, ncolblocks);
     return dtl_gemm_rt<PREC, D, EPI, 4>(c, s, a, ncolblocks);
