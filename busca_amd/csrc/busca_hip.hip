@@ -22,6 +22,7 @@
 #include "reid_kernel.hip.inc"
 #include "reid_gram.hip.inc"
 #include "reid_halo.hip.inc"
+#include "reid_kwave.hip.inc"
 #include "reid_f32.hip.inc"
 #include "dt_tiled.hip.inc"
 #include "ecc_kernel.hip.inc"

@@ -109,7 +109,8 @@ def test_reid_default_large_batch_schedule_vs_reference(ctx, golden_dir, monkeyp
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     from make_golden import smooth_crops
     from busca_amd.reid import ReIDEncoderHIP
-    for k in ("BUSCA_REID_GRAM", "BUSCA_REID_HALO", "BUSCA_REID_FUSE_C1", "BUSCA_REID_SPLITK_BLOCKS", "BUSCA_REID_DIRECT_ROWS"):
+    for k in ("BUSCA_REID_GRAM", "BUSCA_REID_HALO", "BUSCA_REID_FUSE_C1", "BUSCA_REID_SPLITK_BLOCKS", "BUSCA_REID_DIRECT_ROWS",
+              "BUSCA_REID_KWAVE_BLOCKS", "BUSCA_REID_KWAVE_HALO", "BUSCA_REID_KWAVE_NW", "BUSCA_REID_KWAVE_PT"):
         monkeypatch.delenv(k, raising=False)
     ref = np.load(os.path.join(golden_dir, "reid_big.npz"))["feats_n%d_seed%d" % (n, seed)]
     sd = synth.reid_state_dict(3)
@@ -184,6 +185,36 @@ def test_reid_halo_conv_path(ctx, monkeypatch):
     assert np.abs(halo - generic).max() <= 5e-3, np.abs(halo - generic).max()
     assert (halo * generic).sum(1).min() >= 0.9998
     monkeypatch.delenv("BUSCA_REID_HALO")
+    ReIDEncoderHIP(ctx, sd)
+
+
+@pytest.mark.parametrize("n,nw,pt", [(5, 0, 0), (8, 16, 2), (8, 8, 4), (24, 4, 4), (24, 8, 2), (40, 4, 2)])
+def test_reid_kwave_conv_path(ctx, monkeypatch, n, nw, pt):
+    """Small / mid batches run most convs through conv_kwave_kernel (K split across the waves of a workgroup,
+    reid_kwave.hip.inc).  Every (waves, tile) variant against the LDS-tiled schedule (same stored roundings; f32 summation
+    order differs) and, at oracle-sized batches, against the float32 oracle."""
+    from busca_amd.reid import ReIDEncoderHIP
+    from oracle import reid as oreid
+    sd = synth.reid_state_dict(3)
+    crops = _crops(1500 + n, n)
+    monkeypatch.setenv("BUSCA_REID_KWAVE_BLOCKS", "0")
+    tiled = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
+    monkeypatch.setenv("BUSCA_REID_KWAVE_BLOCKS", "100000")    # every eligible conv
+    monkeypatch.setenv("BUSCA_REID_KWAVE_HALO", "100000")      # including the 3x3 convs the halo kernel would take
+    if nw:
+        monkeypatch.setenv("BUSCA_REID_KWAVE_NW", str(nw))
+        monkeypatch.setenv("BUSCA_REID_KWAVE_PT", str(pt))
+    m = ReIDEncoderHIP(ctx, sd)
+    kw = m.forward(crops).cpu().numpy()
+    assert np.array_equal(kw, m.forward(crops).cpu().numpy())              # fixed summation order: reproducible
+    assert np.abs(kw - tiled).max() <= 5e-3, np.abs(kw - tiled).max()
+    assert (kw * tiled).sum(1).min() >= 0.9998
+    if n <= 8:
+        ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
+        assert (kw * ref).sum(1).min() >= COS_MIN
+        assert np.abs(kw - ref).max() <= FEAT_ATOL
+    for k in ("BUSCA_REID_KWAVE_BLOCKS", "BUSCA_REID_KWAVE_HALO", "BUSCA_REID_KWAVE_NW", "BUSCA_REID_KWAVE_PT"):
+        monkeypatch.delenv(k, raising=False)
     ReIDEncoderHIP(ctx, sd)
 
 
