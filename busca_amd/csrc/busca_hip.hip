@@ -23,6 +23,7 @@
 #include "reid_gram.hip.inc"
 #include "reid_halo.hip.inc"
 #include "reid_kwave.hip.inc"
+#include "gemm_glds.hip.inc"
 #include "reid_f32.hip.inc"
 #include "dt_tiled.hip.inc"
 #include "ecc_kernel.hip.inc"
@@ -371,6 +372,35 @@ static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblock
     return dtl_gemm_rt<PREC, D, EPI, 4>(c, s, a, ncolblocks);
 }
 
+// QKV / FFN1 (no row-wise epilogue) in f16 through the direct-to-LDS GEMM of gemm_glds.hip.inc (256-column tiles, staggered wave
+// groups) with BUSCA_DTL_GLDS=1.  Off by default: 512 x 64 x d512 QKV 211 -> 221 us, FFN1 168 -> 161 us - the LDS-DMA path
+// delivers ~20 B/clk/CU, a third of what the VGPR path of dtl_gemm_kernel moves.
+template <int EPI>
+static bool dtl_gemm_glds(busca_ctx* c, hipStream_t s, const DTLArgs& a, int N, int qcols, int* rc_out) {
+    const int on = getenv("BUSCA_DTL_GLDS") ? atoi(getenv("BUSCA_DTL_GLDS")) : 0;      // measured equal to dtl_gemm_kernel (see gemm_glds.hip.inc): opt-in
+    *rc_out = BUSCA_OK;
+    if (!on || N % 256 != 0 || a.K % 32 != 0 || a.K < 96) return false;
+    const long t256 = (long)((a.M + 255) / 256) * (N / 256);
+    if (t256 < 128) return false;
+    GemmGldsArgs g{};
+    g.X = (const _Float16*)a.A; g.ldx = a.lda; g.W = (const _Float16*)a.W; g.ldw = a.K; g.M = a.M; g.N = N; g.K = a.K;
+    g.out = (_Float16*)a.out16; g.ldo = a.ldo; g.bias = a.bias; g.qscale = a.qscale; g.qcols = qcols; g.act = a.act;
+    const bool big = t256 >= 512;
+    const int bm = big ? 256 : 128;
+    g.gridM = (a.M + bm - 1) / bm; g.gridN = N / 256;
+    const unsigned nb = (unsigned)(((g.gridM + 7) / 8) * 8 * g.gridN);
+    const size_t lds = (size_t)4 * (bm * 64 + 256 * 64);
+    TimedLaunch tl(c, s);
+    if (big) {
+        *rc_out = ensure_lds(c, (const void*)gemm_glds_kernel<8, EPI>, lds); if (*rc_out) return true;
+        hipLaunchKernelGGL((gemm_glds_kernel<8, EPI>), dim3(nb), dim3(512), lds, s, g);
+    } else {
+        *rc_out = ensure_lds(c, (const void*)gemm_glds_kernel<4, EPI>, lds); if (*rc_out) return true;
+        hipLaunchKernelGGL((gemm_glds_kernel<4, EPI>), dim3(nb), dim3(512), lds, s, g);
+    }
+    return true;
+}
+
 template <int PREC, int D, int MT>
 static int dtl_attention(busca_ctx* c, hipStream_t s, const void* qkv, void* O, int B, int T, float* att) {
     constexpr int ES = Prec<PREC>::ES, HD = D / 4, TPK = Prec<PREC>::CHUNK * Prec<PREC>::nchunks(MT);
@@ -446,13 +476,21 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     for (int l = 0; l < K.nlayers; ++l) {
         const DTLayerW& W = K.layer[l];
         a.A = Xop; a.lda = D; a.W = S.tw.w_in[l]; a.K = D; a.bias = W.b_in; a.out16 = QKV; a.ldo = 3 * D;
-        { int rc = dtl_gemm<PREC, D, DTL_EPI_QKV>(c, s, a, 3); if (rc) return rc; }
+        {
+            int rc = BUSCA_OK;
+            if (!(PREC == 1 && dtl_gemm_glds<GEMM_EPI_BIAS_QSCALE>(c, s, a, 3 * D, D, &rc))) rc = dtl_gemm<PREC, D, DTL_EPI_QKV>(c, s, a, 3);
+            if (rc) return rc;
+        }
         float* att = K.att ? K.att + (size_t)l * B * 4 * T * T : nullptr;
         { int rc = dtl_attention_mt<PREC, D>(c, s, MT, QKV, O, B, T, att); if (rc) return rc; }
         a.A = O; a.lda = D; a.W = S.tw.w_out[l]; a.K = D; a.bias = W.b_out; a.gamma = W.g1; a.beta = W.be1;
         { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
         a.A = Xop; a.lda = D; a.W = S.tw.w1[l]; a.K = D; a.bias = W.b1; a.out16 = H; a.ldo = FF;
-        { int rc = dtl_gemm<PREC, D, DTL_EPI_FFN1>(c, s, a, FF / D); if (rc) return rc; }
+        {
+            int rc = BUSCA_OK;
+            if (!(PREC == 1 && dtl_gemm_glds<GEMM_EPI_BIAS_ACT>(c, s, a, FF, 0, &rc))) rc = dtl_gemm<PREC, D, DTL_EPI_FFN1>(c, s, a, FF / D);
+            if (rc) return rc;
+        }
         a.A = H; a.lda = FF; a.W = S.tw.w2[l]; a.K = FF; a.bias = W.b2; a.gamma = W.g2; a.beta = W.be2;
         { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
     }

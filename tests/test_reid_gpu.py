@@ -110,7 +110,8 @@ def test_reid_default_large_batch_schedule_vs_reference(ctx, golden_dir, monkeyp
     from make_golden import smooth_crops
     from busca_amd.reid import ReIDEncoderHIP
     for k in ("BUSCA_REID_GRAM", "BUSCA_REID_HALO", "BUSCA_REID_FUSE_C1", "BUSCA_REID_SPLITK_BLOCKS", "BUSCA_REID_DIRECT_ROWS",
-              "BUSCA_REID_KWAVE_BLOCKS", "BUSCA_REID_KWAVE_HALO", "BUSCA_REID_KWAVE_NW", "BUSCA_REID_KWAVE_PT"):
+              "BUSCA_REID_KWAVE_BLOCKS", "BUSCA_REID_KWAVE_HALO", "BUSCA_REID_KWAVE_NW", "BUSCA_REID_KWAVE_PT",
+              "BUSCA_REID_GLDS_MIN", "BUSCA_REID_GLDS_BM"):
         monkeypatch.delenv(k, raising=False)
     ref = np.load(os.path.join(golden_dir, "reid_big.npz"))["feats_n%d_seed%d" % (n, seed)]
     sd = synth.reid_state_dict(3)
@@ -214,6 +215,34 @@ def test_reid_kwave_conv_path(ctx, monkeypatch, n, nw, pt):
         assert (kw * ref).sum(1).min() >= COS_MIN
         assert np.abs(kw - ref).max() <= FEAT_ATOL
     for k in ("BUSCA_REID_KWAVE_BLOCKS", "BUSCA_REID_KWAVE_HALO", "BUSCA_REID_KWAVE_NW", "BUSCA_REID_KWAVE_PT"):
+        monkeypatch.delenv(k, raising=False)
+    ReIDEncoderHIP(ctx, sd)
+
+
+@pytest.mark.parametrize("n,bm", [(7, 128), (24, 256), (40, 128)])
+def test_reid_glds_gemm_path(ctx, monkeypatch, n, bm):
+    """Transform-free 1x1 convs (conv1 of the layer-3 / layer-4 bottlenecks) as plain GEMMs with direct-to-LDS operand loads
+    (gemm_glds.hip.inc; automatic from 192 tiles = 256 crops).  Forced on at small batches (ragged last row tile included):
+    same stored roundings as the tiled kernel, different f32 summation order."""
+    from busca_amd.reid import ReIDEncoderHIP
+    from oracle import reid as oreid
+    sd = synth.reid_state_dict(3)
+    crops = _crops(1700 + n, n)
+    monkeypatch.setenv("BUSCA_REID_KWAVE_BLOCKS", "0")
+    monkeypatch.setenv("BUSCA_REID_GLDS_MIN", "0")
+    tiled = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
+    monkeypatch.setenv("BUSCA_REID_GLDS_MIN", "1")
+    monkeypatch.setenv("BUSCA_REID_GLDS_BM", str(bm))
+    m = ReIDEncoderHIP(ctx, sd)
+    got = m.forward(crops).cpu().numpy()
+    assert np.array_equal(got, m.forward(crops).cpu().numpy())
+    assert np.abs(got - tiled).max() <= 5e-3, np.abs(got - tiled).max()
+    assert (got * tiled).sum(1).min() >= 0.9998
+    if n <= 8:
+        ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
+        assert (got * ref).sum(1).min() >= COS_MIN
+        assert np.abs(got - ref).max() <= FEAT_ATOL
+    for k in ("BUSCA_REID_KWAVE_BLOCKS", "BUSCA_REID_GLDS_MIN", "BUSCA_REID_GLDS_BM"):
         monkeypatch.delenv(k, raising=False)
     ReIDEncoderHIP(ctx, sd)
 
