@@ -21,6 +21,8 @@ def build(force=False, verbose=False):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
+    if os.environ.get("BUSCA_CONV_PROBE"):      # s_memtime phase stamps in the ReID conv kernels (BUSCA_CONV_TS); costs ~1 %, off by default
+        base.append("-DBUSCA_CONV_PROBE")
     # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs instead of AGPRs, which removes ~1 500 v_accvgpr_* copies from the
     # Decision-Transformer kernels (their epilogues are VALU work on the accumulators): f16 DT-step +7 %, f32 +1-2 %, ReID
     # unchanged (measured A/B on MI355X, round 2).  The pass behind it is young (it crashed on an experimental variant of the
