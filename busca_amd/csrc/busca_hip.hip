@@ -24,6 +24,7 @@
 #include "reid_halo.hip.inc"
 #include "reid_kwave.hip.inc"
 #include "gemm_glds.hip.inc"
+#include "reid_wdirect.hip.inc"
 #include "reid_f32.hip.inc"
 #include "dt_tiled.hip.inc"
 #include "ecc_kernel.hip.inc"
