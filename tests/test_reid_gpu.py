@@ -275,6 +275,29 @@ def test_reid_weights_direct_1x1_path(ctx, monkeypatch, n):
     ReIDEncoderHIP(ctx, sd)
 
 
+@pytest.mark.parametrize("n", [1, 13, 33, 65, 129, 193])
+def test_reid_default_schedule_vs_plain_tiled_schedule(ctx, monkeypatch, n):
+    """Batch sizes on both sides of the launch-time switch-overs (K-split kernel below 192 tiles / 600 MB, half-image halo tiles
+    below 192 crops, Gram statistics from 65 536 pixels, fused tails ...): whatever mix of kernels the default picks must agree
+    with the plain tiled schedule (tools/reid_schedule_soak.py runs the long list)."""
+    from busca_amd.reid import ReIDEncoderHIP
+    sd = synth.reid_state_dict(3)
+    crops = _crops(2100 + n, n)
+    plain_env = {"BUSCA_REID_KWAVE_BLOCKS": "0", "BUSCA_REID_WD_MIN": "0", "BUSCA_REID_HALO_HALF": "0", "BUSCA_REID_GRAM": "0", "BUSCA_REID_FUSE_C1": "0"}
+    for k in plain_env:
+        monkeypatch.delenv(k, raising=False)
+    a = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
+    for k, v in plain_env.items():
+        monkeypatch.setenv(k, v)
+    b = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
+    assert np.isfinite(a).all()
+    assert np.abs(a - b).max() <= 5e-3, np.abs(a - b).max()
+    assert (a * b).sum(1).min() >= 0.9998
+    for k in plain_env:
+        monkeypatch.delenv(k, raising=False)
+    ReIDEncoderHIP(ctx, sd)
+
+
 def test_reid_fused_tail_conv1_path(ctx, monkeypatch):
     """Large batches: the block tails of layers 1-3 also run the next bottleneck's conv1 on the tile they hold
     (tail_conv1_kernel; with the Gram schedule forced on, all seven instantiations run at 96 crops).  The stored tensors
