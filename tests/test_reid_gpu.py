@@ -251,7 +251,7 @@ def test_reid_glds_gemm_path(ctx, monkeypatch, n, bm):
 def test_reid_weights_direct_1x1_path(ctx, monkeypatch, n):
     """Large launches run the 1x1 convs with 256-multiple output channels (conv1 / conv3 statistics pass / fused block tail of
     layers 3-4, conv3 of layer 2) through conv1x1_wd_kernel (weights streamed into MFMA fragments, reid_wdirect.hip.inc;
-    automatic from 512 tiles).  Forced on at small batches with ragged last tiles: same stored roundings as the tiled kernel."""
+    automatic from 256 tiles).  Forced on at small batches with ragged last tiles: same stored roundings as the tiled kernel."""
     from busca_amd.reid import ReIDEncoderHIP
     from oracle import reid as oreid
     sd = synth.reid_state_dict(3)
