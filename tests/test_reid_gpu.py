@@ -277,7 +277,7 @@ def test_reid_weights_direct_1x1_path(ctx, monkeypatch, n):
 
 @pytest.mark.parametrize("n", [1, 13, 33, 65, 129, 193])
 def test_reid_default_schedule_vs_plain_tiled_schedule(ctx, monkeypatch, n):
-    """Batch sizes on both sides of the launch-time switch-overs (K-split kernel below 192 tiles / 600 MB, half-image halo tiles
+    """Batch sizes on both sides of the launch-time switch-overs (K-split kernel below 288 tiles / 600 MB, half-image halo tiles
     below 192 crops, Gram statistics from 65 536 pixels, fused tails ...): whatever mix of kernels the default picks must agree
     with the plain tiled schedule (tools/reid_schedule_soak.py runs the long list)."""
     from busca_amd.reid import ReIDEncoderHIP
