@@ -157,17 +157,17 @@ def roofline_obj(precision, B, L, P, d, ff, timing, bracket_ms_per_call, kernel=
     flops = dt_step_flops(B, L, P, d, ff) * steps
     ach = flops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else float("nan")
     spl = steps / max(1, calls)
-    traffic = None
+    traffic, traffic_note = None, None
     try:    # HBM bytes per launch from the committed PMC run (profiles/pmc_traffic.json), same workload and F
         meta = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        ent = meta.get("dt_%s_F%d_B%d_P%d_d%d" % (precision, int(round(spl)), B, P, d))
-        if ent is None and abs(spl - 8) <= 2:          # 7/7/6-step launches: the 8-step PMC run is the closest measured case
-            ent = meta.get("dt_%s_F8_B%d_P%d_d%d" % (precision, B, P, d))
+        key = "dt_%s_F%d_B%d_P%d_d%d" % (precision, int(round(spl)), B, P, d)
+        ent = meta.get(key) if abs(spl - round(spl)) < 1e-9 else None      # only a PMC run of EXACTLY this launch shape counts
         traffic = ent["hbm_bytes_per_launch"] if ent else None
-    except Exception:
-        traffic = None
+        traffic_note = ent["source"] if ent else "no PMC run of this launch shape (%s, %.2f steps per launch) in profiles/pmc_traffic.json" % (key, spl)
+    except Exception as e:
+        traffic, traffic_note = None, "profiles/pmc_traffic.json unreadable: %r" % (e,)
     return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[precision],
-            "traffic": traffic, "kernel": kernel, "kernel_avg_ms": tot_ms / max(1, nk), "kernel_launches_per_call": nk / max(1, calls),
+            "traffic": traffic, "traffic_note": traffic_note, "kernel": kernel, "kernel_avg_ms": tot_ms / max(1, nk), "kernel_launches_per_call": nk / max(1, calls),
             "kernel_ms_per_call": tot_ms / max(1, calls), "flops_per_call": flops / max(1, calls),
             "steps_per_launch": spl, "event_bracket_ms_per_launch": bracket_ms_per_call,
             "algorithmic_bytes_per_step": dt_step_bytes(B, L, P, d, ff)}
@@ -196,13 +196,15 @@ def config_leg(ctx, dev, name, B, L, P, d, precision, F, steps, seed=7):
                                      kernel="dt_fused_kernel" if fused else "dtl_gemm_kernel + dtl_attention_kernel (whole forward)")}
 
 
-def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None):
+def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None, reid_precision="f16"):
     """ReID (two train-mode-BN batches: B*L memory crops, B*P candidate crops, u8 resident in HBM) + DT.
+    reid_precision "f32" = the exact float32 convs (the reference's arithmetic, busca/reid/resnet.py:266-322); the roofline is
+    then priced against the f32 MFMA peak.
     n_det=None: every candidate slot holds a different crop (worst case).  n_det=k: the B*P candidate slots are filled from k
     distinct detection crops, as a tracker's are (each track takes its P nearest detections, network.py:340-358); the extractor
     then computes each distinct crop once and weights the BatchNorm statistics by its multiplicity (busca_reid_forward_w)."""
     from busca_amd.reid import ReIDEncoderHIP
-    reid = ReIDEncoderHIP(ctx, synth.reid_state_dict(7))
+    reid = ReIDEncoderHIP(ctx, synth.reid_state_dict(7), precision=reid_precision)
     mem = torch.from_numpy(synth.randint_u8(11, "mem", (B * L, 384, 128, 3))).to(dev)
     inverse_d, counts = None, None
     if n_det is None:
@@ -243,17 +245,20 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None):
     traffic = None
     try:    # HBM bytes of the two ReID passes from the committed PMC runs, scaled per crop from the nearest measured batch
         meta = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        per_crop = meta["reid_f16_n512"]["hbm_bytes_per_pass"] / 512.0
+        per_crop = meta["reid_%s_n512" % reid_precision]["hbm_bytes_per_pass"] / 512.0
         traffic = per_crop * crops
     except Exception:
         traffic = None
+    peak = PEAK_TFLOPS[reid_precision]
     return {"value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "crop_slots_per_step": slots, "crops_per_step": crops,
             "candidate_crops": "all distinct" if n_det is None else "%d slots drawn from %d detections (repeats computed once, weighted statistics)" % (B * P, n_det),
             "reid_algorithmic_tflop_per_step": crops * REID_GFLOP_PER_CROP / 1e3,
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["f16"], "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS["f16"],
+            "dtype": reid_precision, "dt_dtype": dt_model.precision,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                          "traffic": traffic, "hbm_time_floor_ms": (traffic / 6.3e12 * 1e3) if traffic else None,
-                         "note": "ReID convs (fp16 MFMA, f32 accumulate) + DT over the whole step; u8 crops already in HBM; traffic = PMC "
-                                 "FETCH_SIZE x2 + WRITE_SIZE of a 512-crop pass (profiles/r02_reid_n512_pmc_traffic*.txt) scaled per crop"},
+                         "note": "ReID convs (%s MFMA operands, f32 accumulate) + DT over the whole step; u8 crops already in HBM; traffic = PMC "
+                                 "FETCH_SIZE x2 + WRITE_SIZE of a 512-crop pass (profiles/*reid_n512_pmc_traffic*.txt) scaled per crop, null "
+                                 "when no PMC run of this flavour is committed" % ("fp16" if reid_precision == "f16" else "float32")},
             "steps": n_steps}
 
 
@@ -270,6 +275,13 @@ def assoc_e2e(frames):
                                                                           "busca_frames_per_s", "device_resident_crops")}
     import gc
     gc.collect(); torch.cuda.empty_cache()      # the previous scenes' models / crop pools go away before the next one is timed
+    try:        # the reference's own arithmetic: exact-f32 ReID + f32 Decision Transformer (the flavour with <= 1e-3 parity)
+        for lost, objs in ((32, 150), (8, 60)):
+            r = e2e_sim.run(lost, objs, 5, 512, "f32", max(5, frames // 2), verbose=False, reid_precision="f32")
+            out["f32_lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in ("p50_assoc_latency_ms", "busca_frames_per_s", "precision", "reid_precision")}
+            gc.collect(); torch.cuda.empty_cache()
+    except Exception as e:
+        out["f32_lost32_dets118"] = {"error": repr(e)}
     r = e2e_sim.run(8, 60, 5, 512, "f16", frames, verbose=False, device_only_crops=True)     # opt-in: crops never copied back to the host
     out["lost8_dets52_device_only_crops"] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "busca_frames_per_s")}
     gc.collect(); torch.cuda.empty_cache()
@@ -277,8 +289,94 @@ def assoc_e2e(frames):
         out["multi_sequence_4x_lost8"] = e2e_sim.run_multi(4, 8, 60, 5, 512, "f16", frames)
     except Exception as e:
         out["multi_sequence_4x_lost8"] = {"error": repr(e)}
-    out["config"] = "shipped model shape d=512 ff=1024 L=11 P=5, f16 MFMA DT + fp16 ReID, random weights, synthetic 1080p frames"
+    out["config"] = ("shipped model shape d=512 ff=1024 L=11 P=5, random weights, synthetic 1080p frames; default keys: f16 MFMA DT + fp16 ReID; "
+                     "f32_* keys: float32 DT + exact-f32 ReID (reference arithmetic)")
     return out
+
+
+def cfg5_split_leg(ctx, dev, rank, world, dist, red_dev, steps, seed=7):
+    """BASELINE configs[4] (512 lost x 64 proposals x d512, f16 MFMA) with ONE step's tracks split over the ranks
+    (SURVEY.md 8e case 2): rank r runs sharding.split_tracks(512, world, r) through busca_dt_forward with replicated weights,
+    the host gathers the slices in rank order (sharding.gather_track_slices) - no collective on the data path.  value = whole
+    steps per second (slowest rank).  Every rank calls this; rank 0 gets the result."""
+    import hashlib
+    from busca_amd import sharding
+    from busca_amd.dt import DecisionTransformerHIP
+    B, L, P, d = 512, 11, 64, 512
+    sd = synth.dt_state_dict(seed, d=d, ff=2 * d)
+    full = synth.dt_inputs(seed, B, L, P)                    # every rank builds the same step, then keeps its slice
+    lo, hi = sharding.split_tracks(B, world, rank)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v[lo:hi])).to(dev) for k, v in full.items()}
+    model = DecisionTransformerHIP(ctx, sd, activation="relu", fake_bbox_f64=True, precision="f16")
+    out = None
+    if hi > lo:
+        model.reserve(hi - lo, L, P)
+
+    def one():
+        return model.forward(t["mem_feat"], t["can_feat"], t["mem_boxes"], t["can_boxes"]) if hi > lo else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(2):
+        out = one()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = one()
+    barrier()
+    el = sharding.max_over_ranks(time.perf_counter() - t0, dist, red_dev)
+    local = out["logits"].cpu().numpy() if out is not None else np.zeros((0, P + 2), np.float32)
+    logits = sharding.gather_track_slices(local, dist)
+    amax = sharding.gather_track_slices(out["argmax"].cpu().numpy() if out is not None else np.zeros((0,), np.int32), dist)
+    if rank != 0:
+        return None
+    assert logits.shape == (B, P + 2) and amax.shape == (B,), (logits.shape, amax.shape)
+    T = L + 2 * (P + 2)
+    fl = dt_step_flops(B, L, P, d, 2 * d)
+    return {"workload": "cfg5 DT-step: 512 lost x 64 proposals x d512 (L=11, T=%d), tracks of ONE step split over %d rank%s" % (T, world, "" if world == 1 else "s"),
+            "dtype": "f16", "value": steps / el, "unit": "steps/s", "steps": steps, "ms_per_step": el / steps * 1e3, "n_gpus": world,
+            "scaling": "strong", "track_slices": sharding.split_tracks(B, world), "collective": "none on the data path (host gather of B x (P+2) logits)",
+            "logits_sha256": hashlib.sha256(np.ascontiguousarray(logits).tobytes()).hexdigest(),
+            "argmax_sha256": hashlib.sha256(np.ascontiguousarray(amax).tobytes()).hexdigest(),
+            "roofline": {"bound": "mfma", "achieved": fl * steps / el / 1e12, "peak": PEAK_TFLOPS["f16"] * world, "unit": "TFLOP/s",
+                         "frac": fl * steps / el / 1e12 / (PEAK_TFLOPS["f16"] * world), "traffic": None,
+                         "note": "whole-step wall time incl. host gather; peak = %d x the per-GPU f16 MFMA peak" % world}}
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (python -m torch.distributed.run), relay
+    rank 0's JSON line and the children's exit code.  This parent never touches the GPU (torch.cuda.device_count() does not
+    initialise it on this image) and never exec()s."""
+    import socket
+    import subprocess
+    backend = os.environ.get("BUSCA_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n:
+        print("bench.py: --gpus %d but only %d GPU(s) visible; refusing to fall back to fewer ranks" % (n, ndev), file=sys.stderr)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if r.returncode != 0:
+        print("bench.py: a rank failed (torch.distributed.run exit code %d)" % r.returncode, file=sys.stderr)
+        return r.returncode
+    if len(lines) != 1:
+        print("bench.py: expected ONE JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
+        return 3
+    print(lines[0], flush=True)
+    return 0
 
 
 def main():
@@ -292,25 +390,35 @@ def main():
     ap.add_argument("--seq-len", type=int, default=11)
     ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("BUSCA_BENCH_PRECISION", "f32"),
                     help="MFMA operand type of the primary line; the other one is reported under `variants`")
-    ap.add_argument("--inflight", type=int, default=8, help="independent steps handed to one C-ABI call")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="independent steps handed to one C-ABI call; 0 = automatic: the K timed steps as ceil(K/64) launches of "
+                         "near-equal size, so a short run is ONE launch whose workgroups back-fill the CUs round after round")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--latency-samples", type=int, default=1000)
     ap.add_argument("--full-steps", type=int, default=6, help="full steps (ReID + DT) timed for `full_step` (0 = skip)")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary-precision / full-step / end-to-end measurements")
     ap.add_argument("--e2e-frames", type=int, default=20, help="frames of the simulated-tracker end-to-end leg (0 = skip)")
+    ap.add_argument("--split-steps", type=int, default=20, help="steps of the cfg5 split-tracks leg (0 = skip)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))      # before anything touches the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     dist = None
     # one rank per GPU.  BUSCA_BENCH_BACKEND=gloo is a TEST mode for boxes with fewer GPUs than ranks: ranks wrap around the
     # visible devices and the bookkeeping (barrier, max over ranks, rank reports) runs over gloo instead of RCCL, so the N > 1
     # code path can be exercised on a 1-GPU box; its numbers mean nothing.
     backend = os.environ.get("BUSCA_BENCH_BACKEND", "nccl")
-    ndev = max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or (backend == "nccl" and ndev < world):
+        print("bench.py: %d rank(s) but %d GPU(s) visible" % (world, ndev), file=sys.stderr)
+        sys.exit(2)
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -325,7 +433,10 @@ def main():
 
     from busca_amd import _lib, sharding
 
-    B, P, L, d, ff, F = args.lost, args.proposals, args.seq_len, args.d, 2 * args.d, max(1, args.inflight)
+    B, P, L, d, ff = args.lost, args.proposals, args.seq_len, args.d, 2 * args.d
+    # steps per launch: with F = 8 a 20-step run was three padded launches (7 + 7 + 6 steps = 224 + 224 + 192 workgroups on 256
+    # CUs, one round each); as ONE 640-workgroup launch the hardware back-fills the CUs and the tail round is the only partial one
+    F = max(1, args.inflight) if args.inflight > 0 else max(1, min(64, args.steps))
     seed = 7   # the reference configs' tracker.seed (config/*/*/*.yml:18)
     sd = synth.dt_state_dict(seed, d=d, ff=ff)
     ctx = _lib.Context(dev_index)
@@ -354,7 +465,7 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, dist, red_dev)
     # who was live: every rank reports (rank, device index, device name, library version, its own elapsed time)
     me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev),
-          "busca_version": int(ctx.lib.busca_version()), "elapsed_s": my_elapsed, "steps": args.steps}
+          "busca_version": int(ctx.lib.busca_version()), "build": _lib.build_info(ctx.lib), "elapsed_s": my_elapsed, "steps": args.steps}
     ranks = [me]
     if dist is not None:
         ranks = [None] * world
@@ -365,6 +476,16 @@ def main():
     if not timing[1]:
         timing = (ev_ms, n_launch, n_launch, args.steps)
     p50 = run.p50_latency_ms(args.latency_samples)
+
+    # ---- BASELINE configs[4] with one step's tracks split over the ranks: every rank takes part ------------------
+    split = None
+    if args.split_steps > 0 and (world > 1 or not args.no_variants or "WORLD_SIZE" in os.environ):
+        try:
+            split = cfg5_split_leg(ctx, dev, rank, world, dist, red_dev, args.split_steps)
+        except Exception as e:
+            if world > 1:
+                raise
+            split = {"error": repr(e)}
 
     result = None
     if rank == 0:
@@ -377,21 +498,21 @@ def main():
             "p50_latency_ms": p50,
             "config": {"workload": "cfgN DT-step: %d lost x %d proposals x d%d (L=%d, T=%d, ff=%d, 4 layers, 4 heads), ReID features "
                                    "precomputed; BASELINE.json configs[1]-shaped batch without the tracker" % (B, P, d, L, L + 2 * (P + 2), ff),
-                       "lost": B, "proposals": P, "d": d, "seq_len": L, "steps_in_flight_per_launch": F,
+                       "lost": B, "proposals": P, "d": d, "seq_len": L, "steps_in_flight_per_launch": F, "launches_in_timed_region": n_launch,
                        "parallelism": "independent sequences sharded per GPU, no collective (%d rank%s)%s" % (
                            world, "" if world == 1 else "s", "" if backend == "nccl" else "; TEST MODE backend=%s, ranks share %d GPU(s)" % (backend, ndev))},
             "roofline": roofline_obj(args.precision, B, L, P, d, ff, timing, ev_ms / max(1, n_launch)),
             "ranks": ranks,
         }
+        if split is not None:
+            result["configs"] = {"cfg5_split": split}
     # ---- secondary precision + full step (rank 0, outside the contract's timed region) ---------------------------
     if rank == 0 and not args.no_variants:
         other = "f16" if args.precision == "f32" else "f32"
-        # the f16 flavour packs two tracks per workgroup from 257 tracks on: give it two rounds of workgroups (2F steps)
-        F2 = 2 * F if other == "f16" else F
-        tens2 = tens
-        if F2 != F:
-            big2 = synth.dt_inputs(seed + 1000 * rank, B * F2, L, P)
-            tens2 = {k: torch.from_numpy(v).to(dev) for k, v in big2.items()}
+        # the f16 flavour packs two tracks per workgroup from 257 tracks on: give it two rounds of workgroups (16 steps)
+        F2 = 16 if other == "f16" else 8
+        big2 = synth.dt_inputs(seed + 1000 * rank, B * F2, L, P)
+        tens2 = {k: torch.from_numpy(v).to(dev) for k, v in big2.items()}
         r2 = DTRunner(ctx, sd, other, tens2, B, L, P, F2, dev)
         k2 = 1600                 # this leg is outside the contract's timed region: its own step count, whole launches only
         r2.run_steps(160)
@@ -408,7 +529,7 @@ def main():
                                       "roofline": roofline_obj(other, B, L, P, d, ff, tm2, el2 / nl2 * 1e3)}}
         # the other BASELINE shapes as their own DT-step lines (cfgR = shipped model shape; cfg4 = BASELINE configs[3];
         # cfg5 = BASELINE configs[4], one GPU's share is the full 512-track step here)
-        cfgs = {}
+        cfgs = result.setdefault("configs", {})
         for name, cB, cP, cd, prec, cF, csteps in (("cfgR", 32, 5, 512, "f32", 8, 400), ("cfgR_f16", 32, 5, 512, "f16", 8, 800),
                                                    ("cfg4", 128, 32, 512, "f32", 2, 20), ("cfg4_f16", 128, 32, 512, "f16", 2, 60),
                                                    ("cfg5", 512, 64, 512, "f16", 1, 20)):
@@ -423,11 +544,23 @@ def main():
             cfgs["cfg4_full_step_expanded_batch"] = cfg4_step.run(3, "f16", dedup=False)
         except Exception as e:
             cfgs["cfg4_full_step"] = {"error": repr(e)}
-        result["configs"] = cfgs
         if args.full_steps > 0:
-            f16_model = r2.model if other == "f16" else DTRunner(ctx, sd, "f16", tens, B, L, P, 1, dev).model
-            result["full_step"] = full_step(ctx, f16_model, B, L, P, args.full_steps, dev)
-            result["full_step_tracker_like_candidates"] = full_step(ctx, f16_model, B, L, P, args.full_steps, dev, n_det=118)
+            dt16 = r2.model if other == "f16" else DTRunner(ctx, sd, "f16", tens, B, L, P, 1, dev).model
+            result["full_step"] = full_step(ctx, dt16, B, L, P, args.full_steps, dev)
+            result["full_step_tracker_like_candidates"] = full_step(ctx, dt16, B, L, P, args.full_steps, dev, n_det=118)
+            # the same step in the REFERENCE's arithmetic: exact-f32 ReID convs (<= 1e-4 against the reference's own features) +
+            # the f32 Decision Transformer, priced against the f32 MFMA peak.  Its own context: a busca_ctx holds one ReID weight set.
+            try:
+                ctx32 = _lib.Context(dev_index)
+                dt32 = run.model if args.precision == "f32" else r2.model
+                from busca_amd.dt import DecisionTransformerHIP
+                dt32 = DecisionTransformerHIP(ctx32, sd, activation="relu", fake_bbox_f64=True, precision="f32")
+                n32 = max(2, args.full_steps // 2)
+                result["full_step_f32"] = full_step(ctx32, dt32, B, L, P, n32, dev, reid_precision="f32")
+                result["full_step_f32_tracker_like_candidates"] = full_step(ctx32, dt32, B, L, P, n32, dev, n_det=118, reid_precision="f32")
+                ctx32.close()
+            except Exception as e:
+                result["full_step_f32"] = {"error": repr(e)}
     if rank == 0:
         if args.cpu_seconds > 0:
             one = {k: v[:B] for k, v in big.items()}

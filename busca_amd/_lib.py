@@ -21,6 +21,9 @@ class DTCfg(C.Structure):
 _vp, _i32, _sz = C.c_void_p, C.c_int32, C.c_size_t
 SIGNATURES = {
     "busca_version": (C.c_int, []),
+    "busca_build_info": (C.c_char_p, []),
+    "busca_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
+    "busca_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32)]),
     "busca_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "busca_ctx_destroy": (None, [_vp]),
     "busca_last_error": (C.c_char_p, [_vp]),
@@ -47,6 +50,7 @@ SIGNATURES = {
     "busca_reid_load_weights_ex": (C.c_int, [_vp, _vp, _sz, _i32]),
     "busca_reid_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "busca_reid_workspace_bytes": (_sz, [_i32]),
+    "busca_reid_reserve": (C.c_int, [_vp, _i32, _vp]),
     "busca_bn_stats_1x1": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
 }
 
@@ -77,6 +81,11 @@ class BuscaError(RuntimeError):
     pass
 
 
+def build_info(lib=None):
+    """The flag set the loaded library was compiled with (busca_build_info)."""
+    return (lib or load()).busca_build_info().decode()
+
+
 class Context:
     """One busca_ctx per process/GPU."""
 
@@ -93,6 +102,15 @@ class Context:
     def check(self, rc):
         if rc != 0:
             raise BuscaError("libbusca_hip error %d: %s" % (rc, self.lib.busca_last_error(self.h).decode()))
+
+    def set_option(self, name, value):
+        """Developer option of this context (include/busca_hip.h: busca_set_option)."""
+        self.check(self.lib.busca_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = _i32(0)
+        self.check(self.lib.busca_get_option(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:

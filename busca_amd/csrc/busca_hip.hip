@@ -46,9 +46,28 @@ struct DTState {
     void* ws = nullptr; size_t ws_bytes = 0;   // tiled-path activation workspace
 };
 
+// Developer options of one context.  Defaults come from the environment ONCE, when the context is created; afterwards they
+// change only through busca_set_option (so a test can flip a flavour between two forwards, and no forward calls getenv).
+struct BuscaOptions {
+    int dt_ntrk = 0;          // BUSCA_DT_NTRK: tracks per workgroup of the f16 fused kernel (0 = automatic: 2 from B > 256, d = 256)
+    int dt_tiled = 0;         // BUSCA_DT_TILED: force the layer-wise Decision-Transformer path
+    int dtl_rt = 0;           // BUSCA_DTL_RT: 2 / 4 = 64- / 128-row tiles of the layer-wise GEMMs (0 = automatic)
+    int dtl_rt_mask = -1;     // BUSCA_DTL_RT_MASK: bit EPI = 64-row tiles for that GEMM kind (-1 = off)
+    int dtl_glds = 0;         // BUSCA_DTL_GLDS: QKV / FFN1 through the direct-to-LDS GEMM
+    int dt_prof = 0;          // BUSCA_DT_PROF: phase stamps of the fused kernel (debug)
+    int last_dt_grid = 0, last_dt_ntrk = 0;     // read-only: workgroups / tracks per workgroup of the last fused launch
+    static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+    void from_env() {
+        dt_ntrk = env_int("BUSCA_DT_NTRK", 0); dt_tiled = getenv("BUSCA_DT_TILED") != nullptr ? 1 : 0;
+        dtl_rt = env_int("BUSCA_DTL_RT", 0); dtl_rt_mask = env_int("BUSCA_DTL_RT_MASK", -1); dtl_glds = env_int("BUSCA_DTL_GLDS", 0);
+        dt_prof = getenv("BUSCA_DT_PROF") != nullptr ? 1 : 0;
+    }
+};
+
 struct busca_ctx {
     int device = 0;
     std::string err;
+    BuscaOptions opt;
     DTState dt;
     ReidState reid;
     // kernel timing (HIP events on the launch stream)
@@ -107,7 +126,40 @@ extern "C" int busca_ctx_create(int device, busca_ctx** out) {
     if (e != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return BUSCA_EHIP; }
     busca_ctx* c = new busca_ctx();
     c->device = device;
+    c->opt.from_env();
     *out = c;
+    return BUSCA_OK;
+}
+
+#ifndef BUSCA_BUILD_FLAGS
+#define BUSCA_BUILD_FLAGS "unknown"
+#endif
+extern "C" const char* busca_build_info(void) { return "libbusca_hip gfx950 flags: " BUSCA_BUILD_FLAGS; }
+
+extern "C" int busca_set_option(busca_ctx* c, const char* name, int32_t value) {
+    if (!c || !name) return BUSCA_EINVAL;
+    BuscaOptions& o = c->opt;
+    const std::string n(name);
+    if (n == "dt_ntrk") o.dt_ntrk = value;
+    else if (n == "dt_tiled") o.dt_tiled = value;
+    else if (n == "dtl_rt") o.dtl_rt = value;
+    else if (n == "dtl_rt_mask") o.dtl_rt_mask = value;
+    else if (n == "dtl_glds") o.dtl_glds = value;
+    else return fail(c, BUSCA_EINVAL, "busca_set_option: unknown option '%s'", name);
+    return BUSCA_OK;
+}
+extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) {
+    if (!c || !name || !value) return BUSCA_EINVAL;
+    const BuscaOptions& o = c->opt;
+    const std::string n(name);
+    if (n == "dt_ntrk") *value = o.dt_ntrk;
+    else if (n == "dt_tiled") *value = o.dt_tiled;
+    else if (n == "dtl_rt") *value = o.dtl_rt;
+    else if (n == "dtl_rt_mask") *value = o.dtl_rt_mask;
+    else if (n == "dtl_glds") *value = o.dtl_glds;
+    else if (n == "last_dt_grid") *value = o.last_dt_grid;
+    else if (n == "last_dt_ntrk") *value = o.last_dt_ntrk;
+    else return fail(c, BUSCA_EINVAL, "busca_get_option: unknown option '%s'", name);
     return BUSCA_OK;
 }
 
@@ -309,14 +361,15 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int PREC, int MT, int D, int FF, int NCH, int NTRK = 1, int OCC2 = 0>
+template <int PREC, int MT, int D, int FF, int NCH, int NTRK = 1>
 static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
     typedef DTLds<PREC, MT, D, FF, 512, NCH, NTRK> LD;
-    static_assert(LD::TOTAL <= 160 * 1024 / (OCC2 ? 2 : 1), "LDS plan exceeds the per-workgroup share of the 160 KiB");
-    auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH, NTRK, OCC2>;
+    static_assert(LD::TOTAL <= 160 * 1024, "LDS plan exceeds the 160 KiB of a CU");
+    auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH, NTRK>;
     const int nwg = (P.B + NTRK - 1) / NTRK;
+    c->opt.last_dt_grid = nwg; c->opt.last_dt_ntrk = NTRK;
     { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
-    static const bool prof = getenv("BUSCA_DT_PROF") != nullptr;   // debug: phase timestamps of workgroup 0
+    const bool prof = c->opt.dt_prof != 0;   // debug: phase timestamps of workgroup 0
     if (prof) {
         DTParams Q = P;
         long long* d = nullptr;
@@ -361,8 +414,7 @@ static int dtl_gemm_rt(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolbl
 // when the tile fits twice into the LDS (d <= 512); BUSCA_DTL_RT=4 / 2 forces either geometry.
 template <int PREC, int D, int EPI>
 static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblocks) {
-    static const int rt_env = getenv("BUSCA_DTL_RT") ? atoi(getenv("BUSCA_DTL_RT")) : 0;
-    static const int rt_mask = getenv("BUSCA_DTL_RT_MASK") ? atoi(getenv("BUSCA_DTL_RT_MASK")) : -1;     // bit EPI = 64-row tiles for that GEMM
+    const int rt_env = c->opt.dtl_rt, rt_mask = c->opt.dtl_rt_mask;      // bit EPI of the mask = 64-row tiles for that GEMM kind
     // default: 64-row tiles only when 128-row tiles would fill less than half the chip (fewer than 128 workgroups) - measured
     // 128 lost x 32 proposals x d512 (79 row blocks): 64-row tiles for the single-column-block GEMMs 0.93 -> 0.86 ms (f16), f32
     // 3.38 -> 2.9 ms; from 158 row blocks on (two such steps in flight) 64-row tiles LOSE 5-10 %, and at >= 256 workgroups
@@ -378,7 +430,7 @@ static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblock
 // delivers ~20 B/clk/CU, a third of what the VGPR path of dtl_gemm_kernel moves.
 template <int EPI>
 static bool dtl_gemm_glds(busca_ctx* c, hipStream_t s, const DTLArgs& a, int N, int qcols, int* rc_out) {
-    const int on = getenv("BUSCA_DTL_GLDS") ? atoi(getenv("BUSCA_DTL_GLDS")) : 0;      // measured equal to dtl_gemm_kernel (see gemm_glds.hip.inc): opt-in
+    const int on = c->opt.dtl_glds;      // measured equal to dtl_gemm_kernel (see gemm_glds.hip.inc): opt-in
     *rc_out = BUSCA_OK;
     if (!on || N % 256 != 0 || a.K % 32 != 0 || a.K < 96) return false;
     const long t256 = (long)((a.M + 255) / 256) * (N / 256);
@@ -525,17 +577,15 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     const int MT = (K.T + 15) / 16;
     const int d = c->dt.cfg.d, prec = c->dt.cfg.precision;
     hipStream_t s = (hipStream_t)stream;
-    const bool force_tiled = getenv("BUSCA_DT_TILED") != nullptr;          // testing: run the layer-wise path on any shape
+    const bool force_tiled = c->opt.dt_tiled != 0;          // testing: run the layer-wise path on any shape
     const bool fused_ok = !force_tiled && P + 2 <= 64;
     // f16: the fused kernel is bound by its weight stream, so from two rounds of workgroups on (B > 256 CUs) every workgroup
     // takes TWO tracks and each streamed weight fragment feeds twice the tokens (BUSCA_DT_NTRK=1/2 forces either)
-    static const int ntrk_env = getenv("BUSCA_DT_NTRK") ? atoi(getenv("BUSCA_DT_NTRK")) : 0;
+    const int ntrk_env = c->opt.dt_ntrk;
     const bool two = ntrk_env == 2 || (ntrk_env == 0 && B > 256);
 #define DT_CASE2(M, DD, NCH) if (fused_ok && two && prec == 1 && MT == M && d == DD) return dt_launch<1, M, DD, 2 * DD, NCH, 2>(c, K, s)
     DT_CASE2(3, 256, 1); DT_CASE2(2, 256, 1);        // d = 512: the parked f32 residual does not fit the LDS plan
 #undef DT_CASE2
-    static const int occ2_env = getenv("BUSCA_DT_OCC2") ? atoi(getenv("BUSCA_DT_OCC2")) : 0;
-    if (fused_ok && occ2_env && prec == 1 && MT == 3 && d == 256) return dt_launch<1, 3, 256, 512, 1, 1, 1>(c, K, s);
 #define DT_CASE(PR, M, DD, NCH) if (fused_ok && prec == PR && MT == M && d == DD) return dt_launch<PR, M, DD, 2 * DD, NCH>(c, K, s)
     DT_CASE(0, 1, 64, 1); DT_CASE(0, 1, 256, 1); DT_CASE(0, 1, 512, 1); DT_CASE(1, 1, 64, 1); DT_CASE(1, 1, 256, 1); DT_CASE(1, 1, 512, 1);
     DT_CASE(0, 2, 64, 1); DT_CASE(0, 3, 64, 1); DT_CASE(0, 4, 64, 1);

@@ -45,6 +45,15 @@ void busca_ctx_destroy(busca_ctx* ctx);
 const char* busca_last_error(const busca_ctx* ctx);
 /* Library/ABI version: major*1000 + minor. */
 int busca_version(void);
+/* The compiler flags this library was built with (busca_amd/build.py passes them in; bench.py records the string). */
+const char* busca_build_info(void);
+/* Developer options of one context (kernel-flavour selection for A/B runs and the tests that compare flavours).  Defaults are read
+ * from the environment ONCE, at busca_ctx_create (BUSCA_DT_NTRK, BUSCA_DT_TILED, BUSCA_DTL_RT, BUSCA_DTL_RT_MASK, BUSCA_DTL_GLDS);
+ * no forward reads the environment.  Names: "dt_ntrk" (0 auto / 1 / 2 tracks per workgroup of the f16 fused kernel), "dt_tiled"
+ * (1 = force the layer-wise path), "dtl_rt" (0 auto / 2 / 4), "dtl_rt_mask" (-1 off), "dtl_glds" (0 / 1); busca_get_option also
+ * answers "last_dt_grid" / "last_dt_ntrk" (workgroups and tracks per workgroup of the last fused launch).  Unknown name: BUSCA_EINVAL. */
+int busca_set_option(busca_ctx* ctx, const char* name, int32_t value);
+int busca_get_option(busca_ctx* ctx, const char* name, int32_t* value);
 
 /* ---- Decision Transformer (busca/network.py:176-244 without the ReID stage) ----------------- */
 typedef struct {
@@ -209,6 +218,10 @@ int busca_reid_forward_w(busca_ctx* ctx, const uint8_t* crops, int32_t n, const 
                          float* feats, void* stream);
 /* Bytes of device workspace busca_reid_forward needs for n crops (allocated lazily inside the ctx). */
 size_t busca_reid_workspace_bytes(int32_t n);
+/* Size the workspace that forwards on `stream` use for batches of up to n crops NOW (counterpart of busca_dt_reserve), so that no
+ * later busca_reid_forward* call on that stream synchronises the device and allocates.  Needs loaded weights (the element size
+ * follows the loaded precision).  One workspace per calling stream, at most 4 streams. */
+int busca_reid_reserve(busca_ctx* ctx, int32_t n, void* stream);
 /*
  * Building block of the large-batch ReID schedule, exposed for unit tests: train-mode BatchNorm (scale, shift) of a
  * 1x1 conv y = w x of stride `stride` WITHOUT running the conv, from the Gram matrix of its input

@@ -4,6 +4,7 @@
 
     python tests/golden/make_golden.py            # all sets
     python tests/golden/make_golden.py dt geom    # selected sets
+    python tests/golden/make_golden.py reid_cfg4                              # round-3 set: 1 408-crop BatchNorm batches (~30 GB RAM, minutes)
     python tests/golden/make_golden.py dt512 assoc512 assoc_select reid_big   # round-2 sets (dt512/assoc512 need ~20 GB RAM;
                                                                               # not part of the default "all")
 
@@ -302,6 +303,48 @@ def make_reid_big(ref):
     make_reid(ref, cases=REID_BIG_CASES, fname="reid_big.npz")
 
 
+REID_CFG4_N, REID_CFG4_SEED = 1408, 2408            # BASELINE configs[3]: 128 lost x 11 memory crops = one 1 408-crop BatchNorm batch
+REID_CFG4_DUP = (1408, 55, 2409)                     # 1 408 candidate slots over 55 distinct crops: the MOT20 duplication ratio 4 096 / 160
+
+
+def cfg4_dup_indices():
+    """Which distinct crop fills each slot of the duplicated batch (every distinct crop at least once, then seeded draws)."""
+    slots, distinct, seed = REID_CFG4_DUP
+    extra = synth.randint_u8(seed, "dup", (slots - distinct, 2)).astype(np.int64)
+    return np.concatenate([np.arange(distinct), (extra[:, 0] * 256 + extra[:, 1]) % distinct])
+
+
+def make_reid_cfg4(ref):
+    """cfg4-sized BatchNorm batches through the reference's own ReID_Encoder (about 11 TFLOP each on the CPU; needs ~30 GB of RAM):
+    (a) 1 408 distinct crops; (b) 1 408 slots filled from 55 distinct crops, expanded on the CPU exactly as the reference's
+    associate_embeddings would build the batch - the features of the 55 distinct crops (first occurrence) are kept."""
+    ref_network = ref[0]
+    enc = ref_network.ReID_Encoder(num_classes=299, device=torch.device("cpu"), pretrained_path="no",
+                                   use_domain_adaptation=True, trainable=False, use_checkpointing=False)
+    load_reid_weights(enc, 3)
+
+    def run(crops):
+        x = crops.astype(np.float32) / 255.0
+        x -= np.array([0.406, 0.456, 0.485])
+        x /= np.array([0.225, 0.224, 0.299])
+        xt = torch.from_numpy(x).float()[..., [2, 1, 0]].permute(0, 3, 1, 2)
+        del x
+        with torch.no_grad():
+            _, feats = enc(xt)
+        return feats.numpy()
+
+    out = {}
+    out["feats_n%d_seed%d" % (REID_CFG4_N, REID_CFG4_SEED)] = run(smooth_crops(REID_CFG4_SEED, REID_CFG4_N))
+    slots, distinct, seed = REID_CFG4_DUP
+    idx = cfg4_dup_indices()
+    feats = run(smooth_crops(seed, distinct)[idx])
+    first = np.array([int(np.argmax(idx == k)) for k in range(distinct)])
+    assert np.abs(feats - feats[first][idx]).max() == 0.0         # copies of a crop get identical features
+    out["dupfeats_slots%d_distinct%d_seed%d" % (slots, distinct, seed)] = feats[first]
+    np.savez_compressed(os.path.join(OUT, "reid_cfg4.npz"), **out)
+    print("wrote reid_cfg4.npz", {k: v.shape for k, v in out.items()})
+
+
 def make_reid(ref, cases=((3, 43), (5, 45)), fname="reid.npz"):
     ref_network = ref[0]
     enc = ref_network.ReID_Encoder(num_classes=299, device=torch.device("cpu"), pretrained_path="no",
@@ -497,7 +540,7 @@ def main():
     if "assoc512" in which:
         make_assoc512(ref)
         _MODELS.pop((512, 1024), None)
-    for name in ("enc", "enc_big", "geom", "assoc", "assoc_select", "assoc_nonorm", "reid", "reid_big", "track"):
+    for name in ("enc", "enc_big", "geom", "assoc", "assoc_select", "assoc_nonorm", "reid", "reid_big", "reid_cfg4", "track"):
         fn = globals().get("make_" + name)
         if name in which and fn is not None:
             fn(ref)

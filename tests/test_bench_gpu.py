@@ -29,20 +29,58 @@ def test_bench_contract_single_gpu():
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and d["higher_is_better"] is True
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
-    assert abs(rf["steps_per_launch"] - 20 / 3) < 1e-9                     # 7 + 7 + 6: the roofline counts the steps really processed
+    assert rf["steps_per_launch"] == 20 and d["config"]["launches_in_timed_region"] == 1     # K steps = ONE 640-workgroup launch
+    assert "traffic" in rf and (rf["traffic"] is not None or "no PMC run" in rf["traffic_note"])          # never a neighbouring shape's number
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "steps/s"
     assert abs(d["value"] - 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
 
 
+def _check_two_ranks(d):
+    assert d["n_gpus"] == 2 and len(d["ranks"]) == 2 and {x["rank"] for x in d["ranks"]} == {0, 1}
+    assert all(x["busca_version"] >= 1000 and x["steps"] == 16 and "gfx950" in x["build"] for x in d["ranks"])
+    assert abs(d["value"] - 2 * 16 / (d["ms_per_step"] * 16 / 1e3)) / d["value"] < 1e-6       # whole-job steps / slowest rank's time
+    assert "TEST MODE" in d["config"]["parallelism"]
+
+
 def test_bench_two_ranks_code_path():
+    """Launched the way the driver does for N > 1 (python -m torch.distributed.run ... bench.py --gpus 2)."""
     env = dict(os.environ, BUSCA_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "8", "--no-variants",
-                        "--cpu-seconds", "0", "--latency-samples", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--cpu-seconds", "0", "--latency-samples", "0", "--split-steps", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and len(d["ranks"]) == 2 and {x["rank"] for x in d["ranks"]} == {0, 1}
-    assert all(x["busca_version"] >= 1000 and x["steps"] == 16 for x in d["ranks"])
-    assert abs(d["value"] - 2 * 16 / (d["ms_per_step"] * 16 / 1e3)) / d["value"] < 1e-6       # whole-job steps / slowest rank's time
-    assert "TEST MODE" in d["config"]["parallelism"]
+    _check_two_ranks(_last_json(r.stdout))
+
+
+def test_bench_self_launches_ranks_and_splits_cfg5():
+    """A plain `python bench.py --gpus 2` starts its own two ranks (child processes; the parent never touches the GPU) and relays ONE
+    JSON line.  The cfg5 split leg (512 lost x 64 proposals x d512, tracks of one step split over the ranks, host gather) must
+    return logits BIT-IDENTICAL to the one-rank run of the same step: a track's result does not depend on which rank, row tile
+    or batch it was computed in."""
+    env = dict(os.environ, BUSCA_BENCH_BACKEND="gloo")
+    common = ["--steps", "16", "--warmup", "8", "--no-variants", "--cpu-seconds", "0", "--latency-samples", "0", "--split-steps", "3"]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    d2 = _last_json(r2.stdout)
+    _check_two_ranks(d2)
+    s2 = d2["configs"]["cfg5_split"]
+    assert s2["n_gpus"] == 2 and s2["track_slices"] == [[0, 256], [256, 512]] and s2["value"] > 0 and s2["scaling"] == "strong"
+    # one rank: the split leg only runs with the variants enabled, so ask for it through a 1-rank launcher run instead
+    env1 = dict(env)
+    r1 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env1)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    s1 = _last_json(r1.stdout)["configs"]["cfg5_split"]
+    assert s1["n_gpus"] == 1 and s1["track_slices"] == [[0, 512]]
+    assert s1["logits_sha256"] == s2["logits_sha256"] and s1["argmax_sha256"] == s2["argmax_sha256"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """Without the test backend, --gpus N on a box with fewer GPUs must fail loudly - never fall back to fewer ranks."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k != "BUSCA_BENCH_BACKEND"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "1", "--no-variants",
+                        "--cpu-seconds", "0", "--latency-samples", "0"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -138,25 +138,42 @@ def test_dt_batch_invariance(ctx):
     assert np.array_equal(part["logits"].cpu().numpy(), full["logits"][10:13])
 
 
-@pytest.mark.parametrize("shape", [(37, 11, 16, 256), (300, 11, 16, 256), (33, 11, 5, 512), (5, 11, 5, 256)])
-def test_two_tracks_per_workgroup_flavour(ctx, monkeypatch, shape):
-    """f16 flavour with TWO tracks per workgroup (each streamed weight fragment feeds both; automatic from B > 256): same
-    results as one track per workgroup up to the float32 association of the residual add, inside the f16 tolerances against
-    the oracle, odd track counts included (the last workgroup's second slot recomputes the last track and stores nothing)."""
+@pytest.mark.parametrize("shape", [(37, 11, 16, 256), (300, 11, 16, 256), (301, 11, 16, 256), (33, 11, 5, 512), (5, 11, 5, 256)])
+def test_two_tracks_per_workgroup_flavour(ctx, shape):
+    """f16 flavour with TWO tracks per workgroup (each streamed weight fragment feeds both; automatic from B > 256): agrees with
+    one track per workgroup to f16 rounding (logits <= 1e-2, measured 3e-3), inside the f16 tolerances against the oracle, odd
+    track counts included (the last workgroup's second slot recomputes the last track and stores nothing)."""
     from oracle import dt as odt
     B, L, P, d = shape
     seed = 400 + B + d
     sd = synth.dt_state_dict(seed, d=d, ff=2 * d)
     inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)
-    monkeypatch.setenv("BUSCA_DT_NTRK", "1")
-    one, _ = _run(ctx, sd, inp, "f16", True, want_hidden=True, want_att=True)
-    monkeypatch.setenv("BUSCA_DT_NTRK", "2")
-    two, _ = _run(ctx, sd, inp, "f16", True, want_hidden=True, want_att=True)
-    assert np.abs(one["logits"] - two["logits"]).max() <= 2e-3
-    assert np.abs(one["att"] - two["att"]).max() <= 1e-4 and np.abs(one["hidden"] - two["hidden"]).max() <= 2e-3
+    # the flavour is a per-context option read at every call (busca_set_option), NOT an environment variable latched by the first
+    # forward of the process; the launch geometry is read back so that this comparison can never silently compare a run with itself
+    try:
+        ctx.set_option("dt_ntrk", 1)
+        one, _ = _run(ctx, sd, inp, "f16", True, want_hidden=True, want_att=True)
+        assert ctx.get_option("last_dt_ntrk") == 1 and ctx.get_option("last_dt_grid") == B
+        ctx.set_option("dt_ntrk", 2)
+        two, _ = _run(ctx, sd, inp, "f16", True, want_hidden=True, want_att=True)
+        if d == 256:        # d = 512 has no two-track flavour (the parked f32 residual does not fit the LDS plan): the request is ignored
+            assert ctx.get_option("last_dt_ntrk") == 2 and ctx.get_option("last_dt_grid") == (B + 1) // 2
+        else:
+            assert ctx.get_option("last_dt_ntrk") == 1
+    finally:
+        ctx.set_option("dt_ntrk", 0)
+    if d == 256:
+        assert not np.array_equal(one["logits"], two["logits"])          # two different kernels really ran
+    # measured on MI355X once the comparison was real (round 3): logits differ by up to 3.1e-3, i.e. f16 rounding of operands
+    # that the two flavours stage at different points - 1/20 of the f16 tolerance against the oracle, not "f32 association only"
+    dl, da, dh = np.abs(one["logits"] - two["logits"]).max(), np.abs(one["att"] - two["att"]).max(), np.abs(one["hidden"] - two["hidden"]).max()
+    print("two-track vs one-track: logits %.2e att %.2e hidden %.2e" % (dl, da, dh))
+    assert dl <= 1e-2 and da <= 1e-3 and dh <= 2e-2, (dl, da, dh)
     assert (two["argmax"] == two["probs"].argmax(-1)).all()
     ref = odt.dt_forward(sd, odt.DTConfig(d=d, ff=2 * d), **inp, return_all=True)
     tol = TOL["f16"]
     assert np.abs(two["logits"] - ref["logits"].numpy()).max() <= tol["logit"]
     assert np.abs(two["probs"] - ref["probs"].numpy()).max() <= tol["prob"]
-    monkeypatch.delenv("BUSCA_DT_NTRK")
+    if B > 256 and d == 256:        # the automatic choice for more than one round of workgroups is the two-track flavour
+        auto, _ = _run(ctx, sd, inp, "f16", True)
+        assert ctx.get_option("last_dt_ntrk") == 2 and np.array_equal(auto["logits"], two["logits"])

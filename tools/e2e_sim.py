@@ -10,8 +10,8 @@ from busca_amd.sim import SimScene
 from busca_amd.tracking import center_distance
 
 
-def run(lost=32, n_obj=150, P=5, d=512, precision="f16", frames=30, verbose=True, device_only_crops=False):
-    args = types.SimpleNamespace(num_layer=4, nhead=4, dim_embedding=512, trans_dim=d, ff_size=2 * d, activation="gelu", dropout_p=0.1,
+def run(lost=32, n_obj=150, P=5, d=512, precision="f16", frames=30, verbose=True, device_only_crops=False, reid_precision="f16"):
+    args = types.SimpleNamespace(reid_precision=reid_precision, num_layer=4, nhead=4, dim_embedding=512, trans_dim=d, ff_size=2 * d, activation="gelu", dropout_p=0.1,
                                  input_flavour="MEM-SEP-CAN-BAD", output_flavour="CAN", encode_separator_as_reference=True,
                                  encode_special_tokens=False, reid_weights_file="no", device=torch.device("cuda:0"), precision=precision, seed=7,
                                  device_only_crops=device_only_crops)
@@ -33,7 +33,7 @@ def run(lost=32, n_obj=150, P=5, d=512, precision="f16", frames=30, verbose=True
         if f >= 3:
             t_crop.append(b - a); t_dist.append(c - b); t_assoc.append(e - c)
     assert probs.shape == (lost, (n_obj - lost) + lost) and rel.all()
-    res = dict(lost=lost, dets=n_obj - lost, proposals=P, d=d, precision=precision, frames=frames,
+    res = dict(lost=lost, dets=n_obj - lost, proposals=P, d=d, precision=precision, reid_precision=reid_precision, frames=frames,
                p50_assoc_latency_ms=float(np.percentile(t_assoc, 50) * 1e3), p50_crop_ms=float(np.percentile(t_crop, 50) * 1e3),
                p50_center_distance_ms=float(np.percentile(t_dist, 50) * 1e3),
                busca_frames_per_s=float(1.0 / np.mean(np.array(t_assoc) + np.array(t_dist))),
