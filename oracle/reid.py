@@ -26,11 +26,13 @@ def _bottleneck(x, sd, p, stride, has_ds):
 
 
 @torch.no_grad()
-def reid_forward(sd, x, return_stages=False):
+def reid_forward(sd, x, return_stages=False, dtype=torch.float32):
     """x: [n,3,384,128] float32 (RGB, CHW, normalised as network.py:470-478,397) -> [n,512] L2-normalised
-    features (resnet.py:266-322 with output_option='plain').  One call == one BN batch."""
-    sd = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in sd.items()}
-    x = torch.as_tensor(x, dtype=torch.float32)
+    features (resnet.py:266-322 with output_option='plain').  One call == one BN batch.
+    dtype=torch.float64 evaluates the same network in double precision (used once, in the build container, to tell the float32
+    round-off of the reference's own CPU kernels from a defect: tests/golden/make_golden.py reid_cfg4_f64)."""
+    sd = {k: torch.as_tensor(np.asarray(v), dtype=dtype) for k, v in sd.items()}
+    x = torch.as_tensor(x).to(dtype)
     stages = {}
     x = F.relu(_bn(F.conv2d(x, sd["conv1.weight"], stride=2, padding=3), sd, "bn1"))
     x = F.max_pool2d(x, 3, 2, 1)

@@ -345,6 +345,18 @@ def make_reid_cfg4(ref):
     print("wrote reid_cfg4.npz", {k: v.shape for k, v in out.items()})
 
 
+def make_reid_cfg4_f64(ref):
+    """The 1 408-crop batch of reid_cfg4 once more in FLOAT64 (oracle/reid.py with dtype=float64, ~45 GB of RAM): the reference's
+    float32 CPU kernels and the HIP extractor's exact-f32 flavour differ by 1.7e-3 on this batch (5e-5 at 200 crops) - this
+    fixture says which of the two is nearer to the exact result."""
+    from oracle import reid as oreid
+    crops = smooth_crops(REID_CFG4_SEED, REID_CFG4_N)
+    x = oreid.crops_to_reid_input(crops)
+    feats = oreid.reid_forward(synth.reid_state_dict(3), x, dtype=torch.float64).numpy()
+    np.savez_compressed(os.path.join(OUT, "reid_cfg4_f64.npz"), **{"feats64_n%d_seed%d" % (REID_CFG4_N, REID_CFG4_SEED): feats.astype(np.float32)})
+    print("wrote reid_cfg4_f64.npz", feats.shape)
+
+
 def make_reid(ref, cases=((3, 43), (5, 45)), fname="reid.npz"):
     ref_network = ref[0]
     enc = ref_network.ReID_Encoder(num_classes=299, device=torch.device("cpu"), pretrained_path="no",
@@ -540,7 +552,7 @@ def main():
     if "assoc512" in which:
         make_assoc512(ref)
         _MODELS.pop((512, 1024), None)
-    for name in ("enc", "enc_big", "geom", "assoc", "assoc_select", "assoc_nonorm", "reid", "reid_big", "reid_cfg4", "track"):
+    for name in ("enc", "enc_big", "geom", "assoc", "assoc_select", "assoc_nonorm", "reid", "reid_big", "reid_cfg4", "reid_cfg4_f64", "track"):
         fn = globals().get("make_" + name)
         if name in which and fn is not None:
             fn(ref)

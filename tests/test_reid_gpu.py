@@ -53,6 +53,29 @@ def test_reid_vs_oracle(model, n):
     assert np.abs(got - ref).max() <= FEAT_ATOL, np.abs(got - ref).max()
 
 
+@pytest.mark.parametrize("n", [3, 40])
+def test_stem_pool_with_negative_batchnorm_scales(ctx, n):
+    """The stem kernel pools the RAW conv output and leaves BatchNorm + ReLU to the consumers (stem_pool_kernel): exact because
+    relu(bn(.)) is monotone per channel - NON-INCREASING where gamma < 0, where the kernel must pool with min instead of max.
+    Random weights have gamma ~ 1, so this case flips the sign of every third stem gamma (and zeroes one) and checks the
+    features against the float32 oracle, in both precisions of the extractor (the f32 flavour keeps the separate pooling pass)."""
+    from busca_amd.reid import ReIDEncoderHIP
+    from oracle import reid as oreid
+    sd = dict(synth.reid_state_dict(3))
+    g = sd["bn1.weight"].copy()
+    g[::3] *= -1.0
+    g[5] = 0.0
+    sd["bn1.weight"] = g
+    crops = _crops(140 + n, n)
+    ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
+    got = ReIDEncoderHIP(ctx, sd, precision="f16").forward(crops).cpu().numpy()
+    cos = (got * ref).sum(1)
+    assert cos.min() >= COS_MIN, cos.min()
+    assert np.abs(got - ref).max() <= FEAT_ATOL, np.abs(got - ref).max()
+    got32 = ReIDEncoderHIP(ctx, sd, precision="f32").forward(crops).cpu().numpy()
+    assert np.abs(got32 - ref).max() <= 5e-5, np.abs(got32 - ref).max()
+
+
 def test_reid_batch_composition_matters(model):
     """Train-mode BN: features depend on the batch they are computed in - and the kernel is
     deterministic for a fixed batch."""
@@ -125,6 +148,41 @@ def test_reid_default_large_batch_schedule_vs_reference(ctx, golden_dir, monkeyp
     # (channels_last vs contiguous input, see oracle/reid.py) already differ by 2.0e-5 at 96 crops; measured here
     # 5.2e-5 at 200 crops -> stated tolerance 1e-4 for these batch sizes (5e-5 stays the bar for the small batches above)
     assert np.abs(got32 - ref).max() <= 1e-4, np.abs(got32 - ref).max()
+
+
+def test_reid_cfg4_sized_batches_vs_reference(ctx, golden_dir):
+    """BASELINE configs[3]-sized BatchNorm batches against features computed by the reference's own ReID_Encoder in the build
+    container (tests/golden/reid_cfg4.npz, make_golden.py reid_cfg4): (a) 1 408 distinct crops through the default large-batch
+    schedule, fp16 and exact-f32 flavours; (b) a 1 408-slot candidate batch drawn from 55 distinct crops (the MOT20 duplication
+    ratio 4 096 / 160): the reference computed the EXPANDED batch, the extractor computes each distinct crop once with weighted
+    statistics (busca_reid_forward_w) - and also the expanded batch itself."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    from busca_amd.reid import ReIDEncoderHIP
+    gold = np.load(os.path.join(golden_dir, "reid_cfg4.npz"))
+    sd = synth.reid_state_dict(3)
+    n, seed = mg.REID_CFG4_N, mg.REID_CFG4_SEED
+    ref = gold["feats_n%d_seed%d" % (n, seed)]
+    crops = torch.from_numpy(mg.smooth_crops(seed, n)).cuda()
+    slots, distinct, dseed = mg.REID_CFG4_DUP
+    dref = gold["dupfeats_slots%d_distinct%d_seed%d" % (slots, distinct, dseed)]
+    idx = mg.cfg4_dup_indices()
+    dcrops = torch.from_numpy(mg.smooth_crops(dseed, distinct)).cuda()
+    counts = np.bincount(idx, minlength=distinct).astype(np.float32)
+    for prec, atol in (("f16", FEAT_ATOL), ("f32", 2e-4)):
+        m = ReIDEncoderHIP(ctx, sd, precision=prec)
+        got = m.forward(crops).cpu().numpy()
+        d = np.abs(got - ref).max()
+        print("cfg4 batch %s: max |delta| %.2e, min cos %.6f" % (prec, d, (got * ref).sum(1).min()))
+        assert d <= atol, d
+        assert (got * ref).sum(1).min() >= (COS_MIN if prec == "f16" else 0.999999)
+        gw = m.forward(dcrops, weights=counts).cpu().numpy()           # 55 crops computed once, statistics weighted by multiplicity
+        dw = np.abs(gw - dref).max()
+        ge = m.forward(dcrops[torch.from_numpy(idx).cuda()]).cpu().numpy()[: distinct]     # the expanded 1 408-slot batch (first occurrences = first 55 rows)
+        de = np.abs(ge - dref).max()
+        print("cfg4 duplicated batch %s: weighted %.2e, expanded %.2e" % (prec, dw, de))
+        assert dw <= atol and de <= atol, (dw, de)
 
 
 @pytest.mark.parametrize("n", [352, 512])

@@ -3,7 +3,7 @@
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-first = sys.argv[2] if len(sys.argv) > 2 else 'stem_halo'
+first = sys.argv[2] if len(sys.argv) > 2 else 'stem_'
 idx = [i for i, r in enumerate(rows) if first in r['Kernel_Name']]
 seq = rows[idx[-1]:]
 t0 = int(seq[0]['Start_Timestamp'])
