@@ -11,6 +11,7 @@
 #include <cstring>
 #include <set>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/busca_hip.h"
@@ -25,6 +26,7 @@
 #include "reid_kwave.hip.inc"
 #include "gemm_glds.hip.inc"
 #include "reid_wdirect.hip.inc"
+#include "reid_pipe.hip.inc"
 #include "reid_f32.hip.inc"
 #include "dt_tiled.hip.inc"
 #include "ecc_kernel.hip.inc"

@@ -170,13 +170,20 @@ def test_reid_cfg4_sized_batches_vs_reference(ctx, golden_dir):
     idx = mg.cfg4_dup_indices()
     dcrops = torch.from_numpy(mg.smooth_crops(dseed, distinct)).cuda()
     counts = np.bincount(idx, minlength=distinct).astype(np.float32)
-    for prec, atol in (("f16", FEAT_ATOL), ("f32", 2e-4)):
+    # The reference's float32 CPU kernels are themselves 1.7e-3 away from a float64 evaluation of the same network on this batch
+    # (tests/golden/reid_cfg4_f64.npz, oracle/reid.py with dtype=float64; 5e-5 at 200 crops): at 4.3 M values per channel its
+    # float32 batch statistics carry that much round-off.  The extractor accumulates statistics in float64, so its exact-f32
+    # flavour is held to 2e-4 against the float64 result and to the reference's own error band (3e-3) against the reference.
+    ref64 = np.load(os.path.join(golden_dir, "reid_cfg4_f64.npz"))["feats64_n%d_seed%d" % (n, seed)]
+    assert 1e-3 < np.abs(ref - ref64).max() < 3e-3
+    for prec, atol in (("f16", FEAT_ATOL), ("f32", 3e-3)):
         m = ReIDEncoderHIP(ctx, sd, precision=prec)
         got = m.forward(crops).cpu().numpy()
-        d = np.abs(got - ref).max()
-        print("cfg4 batch %s: max |delta| %.2e, min cos %.6f" % (prec, d, (got * ref).sum(1).min()))
+        d, d64 = np.abs(got - ref).max(), np.abs(got - ref64).max()
+        print("cfg4 batch %s: max |delta| vs reference %.2e, vs float64 %.2e, min cos %.6f" % (prec, d, d64, (got * ref).sum(1).min()))
         assert d <= atol, d
-        assert (got * ref).sum(1).min() >= (COS_MIN if prec == "f16" else 0.999999)
+        assert d64 <= (FEAT_ATOL if prec == "f16" else 2e-4), d64
+        assert (got * ref).sum(1).min() >= (COS_MIN if prec == "f16" else 0.9999)
         gw = m.forward(dcrops, weights=counts).cpu().numpy()           # 55 crops computed once, statistics weighted by multiplicity
         dw = np.abs(gw - dref).max()
         ge = m.forward(dcrops[torch.from_numpy(idx).cuda()]).cpu().numpy()[: distinct]     # the expanded 1 408-slot batch (first occurrences = first 55 rows)
@@ -301,6 +308,43 @@ def test_reid_glds_gemm_path(ctx, monkeypatch, n, bm):
         assert (got * ref).sum(1).min() >= COS_MIN
         assert np.abs(got - ref).max() <= FEAT_ATOL
     for k in ("BUSCA_REID_KWAVE_BLOCKS", "BUSCA_REID_GLDS_MIN", "BUSCA_REID_GLDS_BM"):
+        monkeypatch.delenv(k, raising=False)
+    ReIDEncoderHIP(ctx, sd)
+
+
+@pytest.mark.parametrize("n", [7, 24])
+def test_reid_pipelined_conv_path(ctx, monkeypatch, n):
+    """conv_pipe_kernel (reid_pipe.hip.inc: weights direct into a three-deep register ring, two LDS activation tiles, one barrier per K
+    step; automatic for the large launches of layers 3-4) forced onto EVERY eligible raw-output conv at small batches - 1x1 and 3x3,
+    stride 1 and 2, 128- and 256-channel tiles, with and without the producer's BatchNorm, ragged last pixel tile: same stored
+    roundings as the tiled kernel, different f32 summation order; weighted statistics too."""
+    from busca_amd.reid import ReIDEncoderHIP
+    from oracle import reid as oreid
+    sd = synth.reid_state_dict(3)
+    crops = _crops(1900 + n, n)
+    knobs = {"BUSCA_REID_KWAVE_BLOCKS": "0", "BUSCA_REID_HALO_MIN": "100000", "BUSCA_REID_WD_MIN": "0", "BUSCA_REID_SPLITK_BLOCKS": "0"}
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("BUSCA_REID_PIPE_MIN", "0")
+    tiled = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
+    monkeypatch.setenv("BUSCA_REID_PIPE_MIN", "1")
+    monkeypatch.setenv("BUSCA_REID_PIPE_ALL", "1")
+    m = ReIDEncoderHIP(ctx, sd)
+    got = m.forward(crops).cpu().numpy()
+    assert np.array_equal(got, m.forward(crops).cpu().numpy())
+    assert not np.array_equal(got, tiled)                               # another kernel really ran
+    assert np.abs(got - tiled).max() <= 5e-3, np.abs(got - tiled).max()
+    assert (got * tiled).sum(1).min() >= 0.9998
+    if n <= 8:
+        ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
+        assert (got * ref).sum(1).min() >= COS_MIN
+        assert np.abs(got - ref).max() <= FEAT_ATOL
+    w = np.ones(n, np.float32); w[::3] = 4
+    idx = np.repeat(np.arange(n), w.astype(int))
+    gw = m.forward(crops, weights=w).cpu().numpy()
+    ge = m.forward(crops[idx]).cpu().numpy()[np.searchsorted(idx, np.arange(n))]
+    assert np.abs(gw - ge).max() <= 5e-3, np.abs(gw - ge).max()
+    for k in list(knobs) + ["BUSCA_REID_PIPE_MIN", "BUSCA_REID_PIPE_ALL"]:
         monkeypatch.delenv(k, raising=False)
     ReIDEncoderHIP(ctx, sd)
 
