@@ -226,7 +226,7 @@ int busca_reid_reserve(busca_ctx* ctx, int32_t n, void* stream);
  * Building block of the large-batch ReID schedule, exposed for unit tests: train-mode BatchNorm (scale, shift) of a
  * 1x1 conv y = w x of stride `stride` WITHOUT running the conv, from the Gram matrix of its input
  * (nn.BatchNorm2d batch statistics, network.py:553-556, of resnet.py:108-128's conv3 / downsample).
- *   x      dev fp16 NHWC [n,H,W,Cin] (Cin 64 or a multiple of 128, <= 512);  in_ss dev f32 [Cin][2] or NULL: when given,
+ *   x      dev fp16 NHWC [n,H,W,Cin] (Cin 64, 128, 256 or 512);  in_ss dev f32 [Cin][2] or NULL: when given,
  *          the conv's input is relu(x*scale+shift) rounded to fp16 (the producer's BatchNorm, applied on the fly)
  *   w      dev fp16 [Cout][Cin];  gamma, beta dev f32 [Cout];  ss_out dev f32 [Cout][2] = (scale, shift), eps 1e-5
  * Synchronises `stream` (scratch is allocated and freed inside the call).
