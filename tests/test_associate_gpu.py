@@ -389,3 +389,23 @@ def test_repeated_crops_are_computed_once(golden_dir):
         assert m.last_unique[0] == m.last_unique[1] and uniq < slots          # the candidate batch really had repeats
         assert np.abs(a - b).max() <= 5e-5, np.abs(a - b).max()
         assert np.abs(a - g["%s_probs_f64_sel0" % name]).max() <= 2e-4
+
+
+def test_fast_flavours_decide_like_the_exact_ones():
+    """tools/decision_agreement.py on 2 000 seeded association steps at the shipped shape (d=512, P=5, Kalman candidates, complete and
+    incomplete memories, candidate batches that repeat detections): the default flavour (float32 DT + fp16 ReID) and the fastest one
+    (f16 DT + fp16 ReID) against the exact one (float32 ReID + float32 DT).  Stated bounds: no probability moves by more than 0.05,
+    so `probs[i, N + i] > busca_thresh` (0.3 / 0.5 in the shipped configs) can only flip for a track whose exact probability lies
+    within 0.05 of the threshold, and the one-hot winner only where the exact top-2 margin is below 0.1.  Random weights put a fifth of
+    all tracks that close to 0.3, i.e. the measured flip rates (about 1 %) are an upper bound for any sharper, trained model."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import decision_agreement as da
+    r = da.run(2000)
+    assert r["steps"] == 2000 and r["tracks"] > 8000 and r["tracks_with_incomplete_memory"] > 3000
+    for c in r["comparisons"]:
+        print(c["flavour"], {k: c[k] for k in ("kalman_gt_0.3", "kalman_gt_0.5", "winner")}, c["abs_delta_prob"]["max"])
+        assert c["abs_delta_prob"]["max"] <= 0.05 and c["abs_delta_prob"]["p99"] <= 0.025
+        for t in ("kalman_gt_0.3", "kalman_gt_0.5"):
+            assert c[t]["flip_rate"] <= 0.02
+            assert c[t]["largest_distance_to_threshold_among_flips"] <= c["abs_delta_kalman_prob"]["max"] + 1e-12
+        assert c["winner"]["largest_exact_margin_among_flips"] <= 2 * c["abs_delta_prob"]["max"] + 1e-12
