@@ -14,6 +14,12 @@ them queue back to back on the two ReID streams.
     batcher.flush()
     probs_a, reliable_a = t1.result()        # bit-identical to model.associate_embeddings(tracks_a, ...)
 
+Bit-identical because the kernel FLAVOUR of a merged launch is pinned to what each step would get alone: the f16 fused kernel
+switches to two tracks per workgroup from 257 tracks on (agrees with the one-track flavour only to f16 rounding, ~3e-3 in the
+logits), so the merged launch of steps that are each below that size is forced to the one-track flavour (`dt_ntrk` option of the
+context) and a step that is itself larger runs in its own launch; the row-tile geometry of the layer-wise path also follows the
+merged size, but its GEMMs sum every row in the same order whatever the tile (`tests/test_bench_gpu.py`, cfg5 split leg).
+
 `submit` takes exactly the arguments of `associate_embeddings` (busca/network.py:282); `result()` flushes if needed.
 """
 import torch
@@ -52,14 +58,24 @@ class StepBatcher:
         groups = {}
         for t in pending:
             groups.setdefault((t._job["L"], t._job["P"]), []).append(t)
+        launches = []
         for (L, P), ts in groups.items():
+            small = [t for t in ts if t._job["B"] <= 256]
+            if small:
+                launches.append((small, 1))                       # one-track flavour, as each of these steps would run alone
+            launches.extend(([t], 0) for t in ts if t._job["B"] > 256)
+        for ts, ntrk in launches:
             feats = [m._assoc_features(t._job) for t in ts]
             dev = feats[0][0].device
             mem_feat = torch.cat([f[0] for f in feats], 0)
             can_feat = torch.cat([f[1] for f in feats], 0)
             mem_ltrb = torch.cat([torch.from_numpy(t._job["mem_ltrb"]) for t in ts], 0).to(dev)
             can_ltrb = torch.cat([torch.from_numpy(t._job["can_ltrb"]) for t in ts], 0).to(dev)
-            out = m._dt.forward(mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=m.store_logits)
+            m._ctx.set_option("dt_ntrk", ntrk)
+            try:
+                out = m._dt.forward(mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=m.store_logits)
+            finally:
+                m._ctx.set_option("dt_ntrk", 0)
             self.launches += 1
             lo = 0
             for t in ts:

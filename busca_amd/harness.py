@@ -353,9 +353,12 @@ def hota(gt, res):
 
 
 def evaluate(results_dir, sequences):
-    """Score result files against the sequences' ground truth.  Uses TrackEval, then motmetrics, when importable (the
-    evaluators the reference calls: GHOST eval_track_eval.py:70, ByteTrack tools/track.py:236-287); otherwise the built-in
-    scorer.  Returns {sequence: metrics dict}."""
+    """Score result files against the sequences' ground truth.  Uses motmetrics when importable (the evaluator ByteTrack calls,
+    adapters/ByteTrack/tools/track.py:236-287: `mm.utils.compare_to_groundtruth` walks the UNION of ground-truth and result
+    frames, so tracker rows in frames without ground truth count as false positives - same here); otherwise the built-in
+    CLEAR-MOT / IDF1 scorer.  HOTA is always the built-in restatement of TrackEval's (GHOST eval_track_eval.py:70 calls the real
+    one; it is not wired in - `trackeval_available()` only tells a caller whether it could run it on the written files itself).
+    Returns {sequence: metrics dict}."""
     out = {}
     for seq in sequences:
         f = os.path.join(results_dir, seq.name + ".txt")
@@ -365,7 +368,7 @@ def evaluate(results_dir, sequences):
         try:
             import motmetrics as mm                       # not in this image; used when present
             acc = mm.MOTAccumulator(auto_id=True)
-            for fr in sorted(set(seq.gt[:, 0].astype(int))):
+            for fr in sorted(set(seq.gt[:, 0].astype(int)) | set(res[:, 0].astype(int))):
                 g, r = seq.gt[seq.gt[:, 0] == fr], res[res[:, 0] == fr]
                 acc.update(g[:, 1].astype(int), r[:, 1].astype(int), mm.distances.iou_matrix(g[:, 2:6], r[:, 2:6], max_iou=0.5))
             s = mm.metrics.create().compute(acc, metrics=["mota", "idf1", "num_switches", "num_false_positives", "num_misses"], name=seq.name)

@@ -219,6 +219,20 @@ class BUSCA:
             self._dirty = False
         return self._ctx
 
+    def reserve(self, max_lost, seq_len=11, num_candidates=5, max_detections=None):
+        """Allocate every workspace a step of up to `max_lost` lost tracks can need NOW (ReID: max_lost x seq_len memory crops on the
+        current stream, max_lost x num_candidates (or max_detections + max_lost distinct) candidate crops on the side stream; layer-wise
+        Decision-Transformer buffers), so that no association step synchronises the device to grow one (busca_reid_reserve /
+        busca_dt_reserve).  Optional: without it the first step of a larger size pays one hipMalloc."""
+        self._sync()
+        dev = self._dev()
+        n_can = max_lost * num_candidates if max_detections is None else min(max_lost * num_candidates, max_detections + max_lost + 1)
+        self._reid.reserve(max_lost * seq_len)
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = _side_stream_of(dev)
+        self._reid.reserve(max(1, n_can), stream=self._side_stream.cuda_stream)
+        self._dt.reserve(max_lost, seq_len, num_candidates)
+
     def _dev(self):
         return torch.device("cuda", self._device_index)
 

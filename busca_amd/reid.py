@@ -36,6 +36,14 @@ class ReIDEncoderHIP:
         if owner is None or owner() is not self:
             self._upload()
 
+    def reserve(self, n, stream=None):
+        """Size the workspace that forwards on `stream` (default: the current stream) use for batches of up to n crops NOW
+        (busca_reid_reserve), so that no later forward synchronises the device and allocates."""
+        self._ensure_loaded()
+        dev = torch.device("cuda", self.ctx.device)
+        s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        self.ctx.check(self.ctx.lib.busca_reid_reserve(self.ctx.h, int(n), s))
+
     def forward(self, crops_u8, stream=None, zero_norm=None, weights=None):
         """`zero_norm` (cuda u8 [n] or None): crops flagged 1 are 0.0 after normalisation (busca_reid_forward_ex).
         `weights` (numpy / sequence of n multiplicities, or None): crop i stands for weights[i] identical crops of the BatchNorm

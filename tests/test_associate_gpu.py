@@ -391,6 +391,32 @@ def test_repeated_crops_are_computed_once(golden_dir):
         assert np.abs(a - g["%s_probs_f64_sel0" % name]).max() <= 2e-4
 
 
+def test_step_batcher_keeps_the_kernel_flavour_of_separate_calls():
+    """Merged steps whose tracks add up to more than 256 (where the f16 fused kernel would switch to two tracks per workgroup) still
+    return what separate calls return, bit for bit: the batcher pins the merged launch to the flavour each step gets alone.  Also
+    BUSCA.reserve: every workspace of the largest step allocated ahead of time."""
+    from busca_amd.batcher import StepBatcher
+    m = _model(256, 512, 31, "f16", "f16")
+    m.reserve(160, 11, 16)
+    jobs = []
+    for k, B in enumerate((150, 140)):
+        inp = synth.dt_inputs(900 + k, B, 11, 16)
+        jobs.append({kk: torch.from_numpy(v).cuda() for kk, v in inp.items()})
+    m._sync()
+    single = [m._dt.forward(j["mem_feat"], j["can_feat"], j["mem_boxes"], j["can_boxes"])["logits"].cpu().numpy() for j in jobs]
+    assert m._ctx.get_option("last_dt_ntrk") == 1
+    cat = {k: torch.cat([j[k] for j in jobs], 0) for k in jobs[0]}
+    auto = m._dt.forward(cat["mem_feat"], cat["can_feat"], cat["mem_boxes"], cat["can_boxes"])["logits"].cpu().numpy()
+    assert m._ctx.get_option("last_dt_ntrk") == 2 and not np.array_equal(auto, np.concatenate(single))      # the automatic choice WOULD differ
+    m._ctx.set_option("dt_ntrk", 1)                            # what StepBatcher.flush does around its merged launch
+    try:
+        pinned = m._dt.forward(cat["mem_feat"], cat["can_feat"], cat["mem_boxes"], cat["can_boxes"])["logits"].cpu().numpy()
+    finally:
+        m._ctx.set_option("dt_ntrk", 0)
+    assert np.array_equal(pinned, np.concatenate(single))
+    assert "set_option(\"dt_ntrk\", ntrk)" in open(StepBatcher.flush.__code__.co_filename).read()
+
+
 def test_fast_flavours_decide_like_the_exact_ones():
     """tools/decision_agreement.py on 2 000 seeded association steps at the shipped shape (d=512, P=5, Kalman candidates, complete and
     incomplete memories, candidate batches that repeat detections): the default flavour (float32 DT + fp16 ReID) and the fastest one
