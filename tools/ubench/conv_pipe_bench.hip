@@ -49,6 +49,17 @@ static void launch_pipe(const PipeArgs& g) {
     const unsigned nb = (unsigned)(((g.gridM + 7) / 8) * 8 * g.gridN);
     hipLaunchKernelGGL((conv_pipe_kernel<NCT, STG, KS>), dim3(nb), dim3(256), 0, 0, g);
 }
+template <int NCT, int STG, int KS>
+static void launch_pipe_nosgb(const PipeArgs& g) {
+    const unsigned nb = (unsigned)(((g.gridM + 7) / 8) * 8 * g.gridN);
+    hipLaunchKernelGGL((conv_pipe_kernel<NCT, STG, KS, false>), dim3(nb), dim3(256), 0, 0, g);
+}
+static bool launch_pipe_nosgb_any(const PipeArgs& g, int nct, int stg, int ks) {
+#define LP(N_, S_, K_) if (nct == N_ && stg == S_ && ks == K_) { launch_pipe_nosgb<N_, S_, K_>(g); return true; }
+    LP(4, STG_BN, 1) LP(4, STG_BN, 3) LP(4, STG_MERGE, 1)
+#undef LP
+    return false;
+}
 static void launch_pipe_any(const PipeArgs& g, int nct, int stg, int ks) {
 #define LP(N_, S_, K_) if (nct == N_ && stg == S_ && ks == K_) { launch_pipe<N_, S_, K_>(g); return; }
     LP(4, STG_PLAIN, 1) LP(4, STG_BN, 1) LP(4, STG_BN, 3) LP(4, STG_MERGE, 1) LP(2, STG_BN, 3) LP(2, STG_MERGE, 1) LP(2, STG_PLAIN, 1) LP(2, STG_BN, 1)
@@ -116,7 +127,9 @@ int main(int argc, char** argv) {
         const double flops = 2.0 * M * c.Cout * (double)K;
         const double us_new = time_it([&] { launch_pipe_any(g, nct, c.stg, c.k); }, 20);
         CK(hipGetLastError());
-        double us_old = 0, us_wd = 0;
+        double us_old = 0, us_wd = 0, us_nosgb = 0;
+        if (launch_pipe_nosgb_any(g, nct, c.stg, c.k)) us_nosgb = time_it([&] { launch_pipe_nosgb_any(g, nct, c.stg, c.k); }, 20);
+        { const double again = time_it([&] { launch_pipe_any(g, nct, c.stg, c.k); }, 20); printf("      pipe with interleave %.1f / %.1f us, without %.1f us\n", us_new, again, us_nosgb); }
         if (c.stg != STG_MERGE && c.Cout >= 128) us_old = time_it([&] { hipLaunchKernelGGL((conv_gemm64_kernel<2, CONV_NORMAL>), dim3(onb), dim3(256), 0, 0, o); }, 20);
         if (c.stg != STG_MERGE && c.k == 1 && c.stride == 1 && c.Cout % 256 == 0) {
             ConvArgs w = o; w.gridN = c.Cout / 256;
