@@ -39,6 +39,9 @@ static const Case CASES[] = {
     {"L4b0c2   3x3s2 512->512 bn   ", 512, 24, 8, 512, 512, 3, 2, STG_BN},
     {"L3ds     1x1s2 512->1024 pl  ", 512, 48, 16, 512, 1024, 1, 2, STG_PLAIN},
     {"small    3x3 64->256 bn tail ", 3, 13, 7, 64, 256, 3, 1, STG_BN},
+    {"L4conv2p 3x3 512->512   plain", 512, 12, 4, 512, 512, 3, 1, STG_PLAIN},
+    {"L4b0c2p  3x3s2 512->512 plain", 512, 24, 8, 512, 512, 3, 2, STG_PLAIN},
+    {"L3b0c2p  3x3s2 256->256 plain", 512, 48, 16, 256, 256, 3, 2, STG_PLAIN},
 };
 
 static unsigned long long rs = 0x9E3779B97F4A7C15ull;
@@ -62,7 +65,7 @@ static bool launch_pipe_nosgb_any(const PipeArgs& g, int nct, int stg, int ks) {
 }
 static void launch_pipe_any(const PipeArgs& g, int nct, int stg, int ks) {
 #define LP(N_, S_, K_) if (nct == N_ && stg == S_ && ks == K_) { launch_pipe<N_, S_, K_>(g); return; }
-    LP(4, STG_PLAIN, 1) LP(4, STG_BN, 1) LP(4, STG_BN, 3) LP(4, STG_MERGE, 1) LP(2, STG_BN, 3) LP(2, STG_MERGE, 1) LP(2, STG_PLAIN, 1) LP(2, STG_BN, 1)
+    LP(4, STG_PLAIN, 1) LP(4, STG_PLAIN, 3) LP(4, STG_BN, 1) LP(4, STG_BN, 3) LP(4, STG_MERGE, 1) LP(2, STG_BN, 3) LP(2, STG_MERGE, 1) LP(2, STG_PLAIN, 1) LP(2, STG_BN, 1)
 #undef LP
     fprintf(stderr, "no instantiation nct=%d stg=%d ks=%d\n", nct, stg, ks); exit(1);
 }
