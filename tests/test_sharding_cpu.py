@@ -98,3 +98,19 @@ def test_two_rank_bookkeeping_gloo():
     assert sorted(m0 + m1) == [0, 1, 2, 3, 4] and not set(m0) & set(m1)
     assert t0 == t1 == 2.0                                         # the bench reports the slowest rank
     assert s0 == s1 == 10.0
+
+
+def test_bench_parent_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` without a launcher is a parent that only counts devices (it never initialises the GPU) and starts the
+    ranks as child processes; with fewer than N devices visible - none in the build container - it must exit non-zero and print no JSON
+    line: never a silent fall-back to fewer ranks (the N > 1 happy path is tests/test_bench_gpu.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    n = torch.cuda.device_count() + 2
+    env = {k: v for k, v in os.environ.items() if k not in ("BUSCA_BENCH_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "1", "--no-variants",
+                        "--cpu-seconds", "0", "--latency-samples", "0"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
