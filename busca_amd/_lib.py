@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbusca_hip.so")
 
 ACT_RELU, ACT_GELU = 0, 1
+LAYOUT_CAN_FIRST, LAYOUT_NO_BAD, LAYOUT_SEP_AS_CAN = 1, 2, 4      # busca_dt_cfg.layout bits
 PREC_F32, PREC_F16 = 0, 1
 PAIR_CENTER, PAIR_CENTER_WEIGHTED, PAIR_IOU, PAIR_IOU_COST = 0, 1, 2, 3
 
@@ -14,7 +15,7 @@ PAIR_CENTER, PAIR_CENTER_WEIGHTED, PAIR_IOU, PAIR_IOU_COST = 0, 1, 2, 3
 class DTCfg(C.Structure):
     _fields_ = [("d", C.c_int32), ("ff", C.c_int32), ("nhead", C.c_int32), ("nlayers", C.c_int32),
                 ("E", C.c_int32), ("activation", C.c_int32), ("fake_bbox_f64", C.c_int32),
-                ("precision", C.c_int32)]
+                ("precision", C.c_int32), ("layout", C.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/busca_hip.h one to one

@@ -110,7 +110,7 @@ static int ensure_lds(busca_ctx* c, const void* kern, size_t bytes) {
     return BUSCA_OK;
 }
 
-extern "C" int busca_version(void) { return 1000; }
+extern "C" int busca_version(void) { return 1001; }
 
 static std::string g_create_err;   // busca_last_error(NULL) reports why busca_ctx_create failed
 
@@ -233,6 +233,7 @@ static bool dt_cfg_ok(const busca_dt_cfg* g) {
     if (g->nhead != 4 || g->nlayers < 1 || g->nlayers > DT_MAX_LAYERS) return false;
     if (g->E != 512 || g->ff != 2 * g->d) return false;
     if (g->precision != BUSCA_PREC_F32 && g->precision != BUSCA_PREC_F16) return false;
+    if (g->layout & ~(BUSCA_LAYOUT_CAN_FIRST | BUSCA_LAYOUT_NO_BAD | BUSCA_LAYOUT_SEP_AS_CAN)) return false;
     return true;
 }
 
@@ -329,6 +330,9 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
     P.lut_xy = (const _Float16*)(base + o_lxy); P.lut_sz = (const _Float16*)(base + o_lsz); P.lut_t = (const _Float16*)(base + o_lt);
     P.lut_c = lut_c;
     P.nlayers = g->nlayers; P.act = g->activation; P.fake_f64 = g->fake_bbox_f64;
+    P.can_pos = (g->layout & BUSCA_LAYOUT_CAN_FIRST) ? 0 : 1; P.nspec = (g->layout & BUSCA_LAYOUT_NO_BAD) ? 1 : 2;
+    P.sep_can = (g->layout & BUSCA_LAYOUT_SEP_AS_CAN) ? 1 : 0;
+    if (P.nspec == 1) P.fake_f64 = 0;    // the float64 promotion comes from torch.cat with the float64 BAD box (encodings.py:127-140): no BAD, no promotion
     S.proto = P;
     S.cfg = *g;
     if (S.dev_tiled) { HIP_TRY(c, hipFree(S.dev_tiled)); S.dev_tiled = nullptr; }
@@ -507,7 +511,7 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     const int T = K.T, B = K.B, L = K.L, P = K.P, FF = 2 * D, E = 512;
     const int MT = (T + 15) / 16;
     if (MT > 9) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most 144 tokens per track (T=%d)", T);
-    if (P + 2 > 128) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most 126 proposals (P=%d)", P);
+    if (P + K.nspec > 128) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most %d proposals (P=%d)", 128 - K.nspec, P);
     const size_t M = (size_t)B * T;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     { int rc = dtl_ws_ensure(c, dtl_ws_bytes(M, D, ES), s); if (rc) return rc; }
@@ -519,9 +523,9 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     char* H = p; p += al(M * FF * ES);
     int* ids = (int*)p;
     const void* Xop = PREC == 0 ? (const void*)X : (const void*)Xh;      // GEMM operand copy of the residual stream
-    hipLaunchKernelGGL(dt_bucket_ids_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, K.mem_ltrb, K.can_ltrb, B, L, P, K.fake_f64, ids);
+    hipLaunchKernelGGL(dt_bucket_ids_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, K.mem_ltrb, K.can_ltrb, B, L, P, K.fake_f64, K.can_pos, K.nspec, K.sep_can, ids);
     DTLArgs a{};
-    a.M = (int)M; a.L = L; a.P = P; a.T = T; a.E = E; a.X = X; a.Xh = Xh; a.act = K.act;
+    a.M = (int)M; a.L = L; a.P = P; a.T = T; a.E = E; a.can_pos = K.can_pos; a.X = X; a.Xh = Xh; a.act = K.act;
     a.qscale = 1.0f / sqrtf((float)(D / 4));
     // embed + assembly + encoding
     a.W = S.tw.w_embed; a.K = E; a.bias = K.b_embed; a.mem_feat = K.mem_feat; a.can_feat = K.can_feat; a.ids = ids;
@@ -550,7 +554,7 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
         { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
     }
     if (K.hidden) HIP_TRY(c, hipMemcpyAsync(K.hidden, X, M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL((dtl_decoder_kernel<D>), dim3(B), dim3(256), 0, s, (const float*)X, T, L, P, K.dec_g, K.dec_b, K.dec_w, K.dec_bias,
+    hipLaunchKernelGGL((dtl_decoder_kernel<D>), dim3(B), dim3(256), 0, s, (const float*)X, T, L, P, K.can_pos, K.nspec, K.dec_g, K.dec_b, K.dec_w, K.dec_bias,
                        K.logits, K.probs, K.argmax);
     HIP_TRY(c, hipGetLastError());
     return BUSCA_OK;
@@ -561,7 +565,7 @@ extern "C" int busca_dt_reserve(busca_ctx* c, int32_t B, int32_t L, int32_t P, v
     if (!c->dt.loaded) return fail(c, BUSCA_ENOWEIGHTS, "busca_dt_reserve before busca_dt_load_weights");
     if (B < 0 || L < 1 || P < 1) return fail(c, BUSCA_EINVAL, "bad shape B=%d L=%d P=%d", B, L, P);
     const size_t es = c->dt.cfg.precision == BUSCA_PREC_F32 ? 4 : 2;
-    return dtl_ws_ensure(c, dtl_ws_bytes((size_t)B * (L + 2 * (P + 2)), c->dt.cfg.d, es), (hipStream_t)stream);
+    return dtl_ws_ensure(c, dtl_ws_bytes((size_t)B * (L + 2 * (P + c->dt.proto.nspec)), c->dt.cfg.d, es), (hipStream_t)stream);
 }
 
 extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
@@ -575,12 +579,12 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     DTParams K = c->dt.proto;
     K.mem_feat = mem_feat; K.can_feat = can_feat; K.mem_ltrb = mem_ltrb; K.can_ltrb = can_ltrb;
     K.logits = logits; K.probs = probs; K.argmax = argmax; K.hidden = hidden; K.att = att;
-    K.B = B; K.L = L; K.P = P; K.T = L + 2 * (P + 2);
+    K.B = B; K.L = L; K.P = P; K.T = L + 2 * (P + K.nspec);
     const int MT = (K.T + 15) / 16;
     const int d = c->dt.cfg.d, prec = c->dt.cfg.precision;
     hipStream_t s = (hipStream_t)stream;
     const bool force_tiled = c->opt.dt_tiled != 0;          // testing: run the layer-wise path on any shape
-    const bool fused_ok = !force_tiled && P + 2 <= 64;
+    const bool fused_ok = !force_tiled && P + K.nspec <= 64;
     // f16: the fused kernel is bound by its weight stream, so from two rounds of workgroups on (B > 256 CUs) every workgroup
     // takes TWO tracks and each streamed weight fragment feeds twice the tokens (BUSCA_DT_NTRK=1/2 forces either)
     const int ntrk_env = c->opt.dt_ntrk;
@@ -614,9 +618,10 @@ extern "C" int busca_dt_bucket_ids(busca_ctx* c, const float* mem_ltrb, const fl
                                    int32_t P, int32_t* ids, void* stream) {
     if (!c || !ids || B < 0 || L < 1 || P < 1) return fail(c, BUSCA_EINVAL, "bad arguments");
     if (B == 0) return BUSCA_OK;
-    const int fake64 = c->dt.loaded ? c->dt.cfg.fake_bbox_f64 : 1;
-    const int n = B * (L + 2 * (P + 2));
-    hipLaunchKernelGGL(dt_bucket_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, mem_ltrb, can_ltrb, B, L, P, fake64, ids);
+    const int fake64 = c->dt.loaded ? c->dt.proto.fake_f64 : 1;
+    const int can_pos = c->dt.loaded ? c->dt.proto.can_pos : 1, nspec = c->dt.loaded ? c->dt.proto.nspec : 2, sep_can = c->dt.loaded ? c->dt.proto.sep_can : 0;
+    const int n = B * (L + 2 * (P + nspec));
+    hipLaunchKernelGGL(dt_bucket_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, mem_ltrb, can_ltrb, B, L, P, fake64, can_pos, nspec, sep_can, ids);
     HIP_TRY(c, hipGetLastError());
     return BUSCA_OK;
 }

@@ -12,15 +12,33 @@ from . import _lib, weights
 
 _PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16}
 _ACT = {"relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU}
+FLAVOURS = ("MEM-SEP-CAN-BAD", "MEM-SEP-CAN", "MEM-CAN-SEP-BAD", "MEM-CAN-SEP")
+
+
+def layout_bits(input_flavour, encode_separator_as_reference=True):
+    """busca_dt_cfg.layout for an input flavour of network.py:103-165 (the CLS-* ones fail inside the reference itself,
+    encodings.py:161, and are refused here)."""
+    if input_flavour not in FLAVOURS:
+        raise NotImplementedError('Input flavour "{}" not implemented'.format(input_flavour))
+    return ((_lib.LAYOUT_CAN_FIRST if "MEM-CAN-SEP" in input_flavour else 0) | (0 if "BAD" in input_flavour else _lib.LAYOUT_NO_BAD)
+            | (0 if encode_separator_as_reference else _lib.LAYOUT_SEP_AS_CAN))
 
 
 class DecisionTransformerHIP:
-    def __init__(self, ctx, state_dict, activation="relu", fake_bbox_f64=True, precision="f32"):
+    def __init__(self, ctx, state_dict, activation="relu", fake_bbox_f64=True, precision="f32", input_flavour="MEM-SEP-CAN-BAD",
+                 encode_separator_as_reference=True):
         self.ctx = ctx
+        self.input_flavour = input_flavour
+        self.nspec = 2 if "BAD" in input_flavour else 1        # appended candidates: NON [, BAD]
+        self.can_pos = 0 if "MEM-CAN-SEP" in input_flavour else 1
+        # the float64 promotion of the candidate-side bucket math comes from torch.cat with the float64 BAD box (encodings.py:21,
+        # 127-140): no BAD token, no promotion
+        fake_bbox_f64 = bool(fake_bbox_f64) and self.nspec == 2
         d, ff, nl, E = weights.dt_dims(state_dict)
         self.d, self.ff, self.nlayers, self.E, self.nhead = d, ff, nl, E, 4
         self.precision = precision
-        self.cfg = _lib.DTCfg(d, ff, 4, nl, E, _ACT[activation], 1 if fake_bbox_f64 else 0, _PREC[precision])
+        self.cfg = _lib.DTCfg(d, ff, 4, nl, E, _ACT[activation], 1 if fake_bbox_f64 else 0, _PREC[precision],
+                              layout_bits(input_flavour, encode_separator_as_reference))
         self._blob = weights.dt_blob(state_dict, nl)
         want = ctx.lib.busca_dt_blob_floats(C.byref(self.cfg))
         if want == 0:
@@ -49,7 +67,7 @@ class DecisionTransformerHIP:
         return t.to(device=dev, dtype=torch.float32).contiguous()
 
     def forward(self, mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=False, want_att=False, stream=None):
-        """-> dict(logits[B,P+2], probs[B,P+2], argmax[B] int32, hidden?[B,T,d], att?[nl,B,4,T,T])."""
+        """-> dict(logits[B,P+2], probs[B,P+2], argmax[B] int32, hidden?[B,T,d], att?[nl,B,4,T,T]); P+1 columns without the BAD token."""
         self._ensure_loaded()
         dev = torch.device("cuda", self.ctx.device)
         mem_feat, can_feat = self._f32(mem_feat, dev), self._f32(can_feat, dev)
@@ -57,8 +75,9 @@ class DecisionTransformerHIP:
         B, L, E = mem_feat.shape
         P = can_feat.shape[1]
         assert E == self.E and can_feat.shape == (B, P, E) and mem_ltrb.shape == (B, L, 4) and can_ltrb.shape == (B, P, 4)
-        T = L + 2 * (P + 2)
-        out = dict(logits=torch.empty(B, P + 2, device=dev), probs=torch.empty(B, P + 2, device=dev),
+        n = P + self.nspec
+        T = L + 2 * n
+        out = dict(logits=torch.empty(B, n, device=dev), probs=torch.empty(B, n, device=dev),
                    argmax=torch.empty(B, dtype=torch.int32, device=dev))
         if want_hidden:
             out["hidden"] = torch.empty(B, T, self.d, device=dev)
@@ -70,6 +89,10 @@ class DecisionTransformerHIP:
             out["logits"].data_ptr(), out["probs"].data_ptr(), out["argmax"].data_ptr(),
             _lib.ptr(out.get("hidden")), _lib.ptr(out.get("att")), s))
         return out
+
+    def can_positions(self, L, P):
+        """Rows of the candidate tokens (incl. NON [, BAD]) in the token sequence (network.py:142,154)."""
+        return [L + 2 * j + self.can_pos for j in range(P + self.nspec)]
 
     def reserve(self, B, L, P):
         """Size the layer-wise path's HBM workspace for (B, L, P) now, so that no later forward allocates (busca_dt_reserve)."""
@@ -83,7 +106,7 @@ class DecisionTransformerHIP:
         mem_ltrb, can_ltrb = self._f32(mem_ltrb, dev), self._f32(can_ltrb, dev)
         B, L, _ = mem_ltrb.shape
         P = can_ltrb.shape[1]
-        ids = torch.empty(B, L + 2 * (P + 2), 3, dtype=torch.int32, device=dev)
+        ids = torch.empty(B, L + 2 * (P + self.nspec), 3, dtype=torch.int32, device=dev)
         s = torch.cuda.current_stream(dev).cuda_stream
         self.ctx.check(self.ctx.lib.busca_dt_bucket_ids(self.ctx.h, mem_ltrb.data_ptr(), can_ltrb.data_ptr(), B, L, P,
                                                        ids.data_ptr(), s))

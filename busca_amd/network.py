@@ -16,7 +16,7 @@ from . import _lib, geometry, synth, tracking, weights
 from .dt import DecisionTransformerHIP
 from .reid import ReIDEncoderHIP
 
-_SUPPORTED_FLAVOUR = "MEM-SEP-CAN-BAD"
+_FLAVOURS = ("MEM-SEP-CAN-BAD", "MEM-SEP-CAN", "MEM-CAN-SEP-BAD", "MEM-CAN-SEP")   # network.py:103-165 without the CLS- ones
 _REID_PREFIX = "reid_encoder.model."
 _PIX_MEAN_RGB = np.array([0.485, 0.456, 0.406], dtype=np.float64)
 _PIX_STD_RGB = np.array([0.299, 0.224, 0.225], dtype=np.float64)
@@ -63,11 +63,19 @@ class BUSCA:
         self.dim_model = args.trans_dim
         if args.activation not in ("relu", "gelu", "tanh", "silu"):
             raise RuntimeError("activation should be relu/gelu/tanh/silu, not {}".format(args.activation))
-        if args.input_flavour != _SUPPORTED_FLAVOUR:
+        if args.input_flavour.startswith("CLS-"):
+            # the reference cannot run these either: PositionalEncoding._get_temporal_ids replaces the index tensor by the int 0
+            # and fails (encodings.py:161; recorded from the reference in tests/golden/flavours_dt.npz)
+            raise NotImplementedError('Input flavour "{}" not implemented (the CLS- flavours fail inside the reference\'s own '
+                                      'positional encoding, busca/encodings.py:161)'.format(args.input_flavour))
+        if args.input_flavour not in _FLAVOURS:
             raise NotImplementedError('Input flavour "{}" not implemented'.format(args.input_flavour))
-        if getattr(args, "output_flavour", "CAN") != "CAN" or not args.encode_separator_as_reference or args.encode_special_tokens:
-            raise NotImplementedError("only output_flavour=CAN, encode_separator_as_reference=true, "
-                                      "encode_special_tokens=false (all shipped configs) are built")
+        if getattr(args, "output_flavour", "CAN") != "CAN":
+            raise NotImplementedError("only output_flavour=CAN (all shipped configs) is built")
+        if args.encode_special_tokens and args.dim_embedding != args.trans_dim:
+            # the learned tokens then have dim_embedding entries and are concatenated, unencoded, with trans_dim-wide rows
+            # (network.py:52-69,128-130): torch.cat raises in the reference
+            raise RuntimeError("Sizes of tensors must match except in dimension 1: encode_special_tokens needs dim_embedding == trans_dim")
         if args.nhead != 4 or args.dim_embedding != 512:
             raise NotImplementedError("nhead must be 4 and dim_embedding 512 (all shipped configs)")
         # The reference's cloned encoder layers run ReLU whatever `activation` says (deepcopy +
@@ -99,7 +107,7 @@ class BUSCA:
         self._reid = None
         self._dirty = True
         seed = int(getattr(args, "seed", 0))
-        sd = OrderedDict(synth.dt_state_dict(seed, d=args.trans_dim, ff=args.ff_size, nlayers=args.num_layer))
+        sd = OrderedDict(synth.dt_state_dict(seed, d=args.trans_dim, ff=args.ff_size, nlayers=args.num_layer, flavour=args.input_flavour))
         reid_sd = None
         path = getattr(args, "reid_weights_file", "no")
         if path is not None and path != "no":
@@ -214,7 +222,9 @@ class BUSCA:
         if self._dirty:
             dt_sd = {k: v for k, v in self._sd.items() if not k.startswith(_REID_PREFIX)}
             self._dt = DecisionTransformerHIP(self._ctx, dt_sd, activation=self.effective_activation,
-                                              fake_bbox_f64=self.pinned_numpy, precision=self.precision)
+                                              fake_bbox_f64=self.pinned_numpy, precision=self.precision,
+                                              input_flavour=self.args.input_flavour,
+                                              encode_separator_as_reference=bool(self.args.encode_separator_as_reference))
             self._reid = ReIDEncoderHIP(self._ctx, self._sd, prefix=_REID_PREFIX, precision=self.reid_precision)
             self._dirty = False
         return self._ctx
@@ -304,7 +314,7 @@ class BUSCA:
         if return_att:
             self.attentions = [out["att"][i] for i in range(out["att"].shape[0])]
         if return_logits:
-            pos = [L + 2 * j + 1 for j in range(P + 2)]
+            pos = self._dt.can_positions(L, P)
             self.logits = out["hidden"][:, pos]
             self.mem_logits = out["hidden"][:, :L].mean(dim=1)
         return out["logits"]
@@ -436,7 +446,7 @@ class BUSCA:
         B, N, K, P, L = job["B"], job["N"], job["K"], job["P"], job["L"]
         self._last = out
         if self.store_logits and "hidden" in out:
-            pos = [L + 2 * j + 1 for j in range(P + 2)]
+            pos = self._dt.can_positions(L, P)
             self.logits = out["hidden"][:, pos]
             self.mem_logits = out["hidden"][:, :L].mean(dim=1)
         probs = out["probs"].cpu().numpy().astype(np.float64)

@@ -23,11 +23,13 @@ def dt_blob_keys(nlayers):
 
 
 def dt_blob(state_dict, nlayers):
-    """Concatenate the Decision-Transformer tensors of a reference state_dict into the C-ABI blob."""
-    missing = [k for k in dt_blob_keys(nlayers) if k not in state_dict]
+    """Concatenate the Decision-Transformer tensors of a reference state_dict into the C-ABI blob.  A model without the BAD token
+    (input_flavour without "-BAD", network.py:66-69) has no `bad_token`: its slot is filled with zeros (BUSCA_LAYOUT_NO_BAD ignores it)."""
+    missing = [k for k in dt_blob_keys(nlayers) if k not in state_dict and k != "bad_token"]
     if missing:
         raise KeyError("state_dict lacks %s" % missing[:4])
-    return np.concatenate([_np(state_dict[k]).ravel() for k in dt_blob_keys(nlayers)])
+    d = _np(state_dict["encoder.weight"]).shape[0]
+    return np.concatenate([_np(state_dict[k]).ravel() if k in state_dict else np.zeros(d, np.float32) for k in dt_blob_keys(nlayers)])
 
 
 def dt_dims(state_dict):

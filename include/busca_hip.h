@@ -66,7 +66,12 @@ typedef struct {
     int32_t fake_bbox_f64; /* 1: candidate-side bucket math in float64 (reference's pinned numpy 1.23.5,
                               busca/tracking.py:12 + busca/encodings.py:21,127); 0: float32 (numpy >= 2) */
     int32_t precision;     /* BUSCA_PREC_* */
+    int32_t layout;        /* BUSCA_LAYOUT_* bits; 0 = MEM-SEP-CAN-BAD with separators encoded as the reference box (every shipped
+                              config).  Selects among the token orders / box encodings of network.py:103-165, encodings.py:112-146 */
 } busca_dt_cfg;
+#define BUSCA_LAYOUT_CAN_FIRST 1   /* input_flavour MEM-CAN-SEP*: each candidate precedes its separator */
+#define BUSCA_LAYOUT_NO_BAD 2      /* input_flavour without -BAD: no BAD token; logits / probs are [B, P+1] (the blob's bad_token is ignored) */
+#define BUSCA_LAYOUT_SEP_AS_CAN 4  /* encode_separator_as_reference = false: a separator is encoded with its candidate's box */
 
 /* Number of float32 values in the flat weight blob for `cfg` (layout below). */
 size_t busca_dt_blob_floats(const busca_dt_cfg* cfg);
@@ -90,7 +95,7 @@ int busca_dt_load_weights(busca_ctx* ctx, const busca_dt_cfg* cfg, const float* 
 /*
  * One association step for B lost tracks x P proposals (replaces BUSCA.forward network.py:203-232,
  * PositionalEncoding.forward encodings.py:43-94 and the softmax/argmax of network.py:403,415-421).
- * All pointers dev.  T = L + 2*(P+2).
+ * All pointers dev.  T = L + 2*(P+2); with BUSCA_LAYOUT_NO_BAD read P+1 for every P+2 below (no BAD column).
  *   mem_feat [B,L,E] f32, can_feat [B,P,E] f32 : ReID features (what reid_encoder returns)
  *   mem_ltrb [B,L,4] f32, can_ltrb [B,P,4] f32 : boxes as passed to BUSCA.forward (ltrb)
  *   logits   [B,P+2] f32  pre-softmax, order [slot_0..slot_{P-1}, NON, BAD]   (required)

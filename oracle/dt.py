@@ -14,8 +14,11 @@ from . import encoding as enc
 
 
 class DTConfig:
-    def __init__(self, d=256, ff=None, nhead=4, nlayers=4, E=512, fake_f64=True, activation="relu"):
+    def __init__(self, d=256, ff=None, nhead=4, nlayers=4, E=512, fake_f64=True, activation="relu", flavour="MEM-SEP-CAN-BAD",
+                 encode_sep_as_ref=True):
         self.d, self.nhead, self.nlayers, self.E = d, nhead, nlayers, E
+        assert flavour in enc.FLAVOURS, flavour
+        self.flavour, self.encode_sep_as_ref = flavour, encode_sep_as_ref     # network.py:103-165, encodings.py:112-146
         self.ff = 2 * d if ff is None else ff
         self.fake_f64 = fake_f64
         # EFFECTIVE activation of the reference is ReLU whatever the YAML says: TransformerEncoder clones
@@ -42,16 +45,24 @@ def prepare(sd):
     return _Prepared(_t(sd))
 
 
-def assemble_tokens(sd, mem_e, can_e):
-    """network.py:103-165 for MEM-SEP-CAN-BAD: [MEM*L, (SEP, CAN_i)*P, SEP, NON, SEP, BAD]; the learned
-    tokens are appended unscaled (:128-130)."""
+def assemble_tokens(sd, mem_e, can_e, flavour="MEM-SEP-CAN-BAD"):
+    """network.py:103-165: [MEM*L, pair_1 .. pair_P, pair(NON) [, pair(BAD)]] with pair = (SEP, CAN) for MEM-SEP-CAN* and (CAN, SEP)
+    for MEM-CAN-SEP*; the learned tokens are appended unscaled (:128-130)."""
     B, P, d = can_e.shape
     sep = sd["sep_token"].view(1, 1, d).expand(B, 1, d)
+    cands = [can_e[:, i:i + 1] for i in range(P)] + [sd["non_token"].view(1, 1, d).expand(B, 1, d)]
+    if "BAD" in flavour:
+        cands.append(sd["bad_token"].view(1, 1, d).expand(B, 1, d))
     toks = [mem_e]
-    for i in range(P):
-        toks += [sep, can_e[:, i:i + 1]]
-    toks += [sep, sd["non_token"].view(1, 1, d).expand(B, 1, d), sep, sd["bad_token"].view(1, 1, d).expand(B, 1, d)]
+    for c in cands:
+        toks += [sep, c] if "MEM-SEP-CAN" in flavour else [c, sep]
     return torch.cat(toks, dim=1)
+
+
+def can_positions(L, P, flavour="MEM-SEP-CAN-BAD"):
+    """network.py:142,154: rows of the candidate tokens (incl. NON [, BAD]) in the assembled sequence."""
+    n = P + (2 if "BAD" in flavour else 1)
+    return [L + 2 * j + (1 if "MEM-SEP-CAN" in flavour else 0) for j in range(n)]
 
 
 def mha(x, w_in, b_in, w_out, b_out, nhead):
@@ -84,7 +95,7 @@ def encoder_layer(x, sd, p, nhead, activation="relu"):
 
 @torch.no_grad()
 def dt_forward(sd, cfg, mem_feat, can_feat, mem_boxes, can_boxes, luts=None, return_all=False):
-    """Features [B,L,E],[B,P,E] + ltrb boxes [B,L,4],[B,P,4] -> logits [B,P+2] (pre-softmax, network.py:244).
+    """Features [B,L,E],[B,P,E] + ltrb boxes [B,L,4],[B,P,4] -> logits [B,P+2] ([B,P+1] without BAD; pre-softmax, network.py:244).
 
     return_all -> dict(logits, probs, argmax, hidden[B,T,d], att[list of B,h,T,T], bucket_ids[B,T,3])."""
     sd = _t(sd)
@@ -98,8 +109,10 @@ def dt_forward(sd, cfg, mem_feat, can_feat, mem_boxes, can_boxes, luts=None, ret
     scale = float(np.sqrt(d))                                   # network.py:203-204
     mem_e = F.linear(mem_feat, sd["encoder.weight"], sd["encoder.bias"]) * scale
     can_e = F.linear(can_feat, sd["encoder.weight"], sd["encoder.bias"]) * scale
-    x = assemble_tokens(sd, mem_e, can_e)                       # [B, T, d]
-    ids = enc.token_bucket_ids(mem_boxes, can_boxes, fake_f64=cfg.fake_f64)
+    flavour = getattr(cfg, "flavour", "MEM-SEP-CAN-BAD")
+    x = assemble_tokens(sd, mem_e, can_e, flavour)              # [B, T, d]
+    ids = enc.token_bucket_ids(mem_boxes, can_boxes, fake_f64=cfg.fake_f64, flavour=flavour,
+                               encode_sep_as_ref=getattr(cfg, "encode_sep_as_ref", True))
     if luts is None:
         luts = enc.build_luts(d)
     x = x + enc.encoding_rows(luts, ids[..., 0], ids[..., 1], ids[..., 2], d)  # encodings.py:87-88
@@ -107,7 +120,7 @@ def dt_forward(sd, cfg, mem_feat, can_feat, mem_boxes, can_boxes, luts=None, ret
     for i in range(cfg.nlayers):
         x, att = encoder_layer(x, sd, "transformer_encoder.layers.%d." % i, cfg.nhead, cfg.activation)
         atts.append(att)
-    pos = [L + 2 * j + 1 for j in range(P + 2)]                 # network.py:142 CAN rows (incl. NON, BAD)
+    pos = can_positions(L, P, flavour)                          # network.py:142 CAN rows (incl. NON, BAD)
     out = x[:, pos]
     out = F.layer_norm(out, (d,), sd["decoder.0.weight"], sd["decoder.0.bias"], 1e-5)
     logits = F.linear(out, sd["decoder.1.weight"], sd["decoder.1.bias"])[:, :, 0]

@@ -55,16 +55,22 @@ def distant_fake_bbox(f64):
     return torch.from_numpy(np.array([m, m, -m / np.float32(100.0), -m / np.float32(100.0)], dtype=np.float32))
 
 
-def insert_fake_bboxes(can_bboxes, ref_bbox, fake_f64=True, encode_sep_as_ref=True):
-    """encodings.py:97-148 for flavour MEM-SEP-CAN-BAD: [ref|can_i]*P, [ref, ref] (SEP, NON),
-    [fake, fake] (SEP, BAD).  torch.cat promotes to float64 when the fake bbox is float64."""
+FLAVOURS = ("MEM-SEP-CAN-BAD", "MEM-SEP-CAN", "MEM-CAN-SEP-BAD", "MEM-CAN-SEP")   # the CLS-* ones fail inside the reference itself (encodings.py:161)
+
+
+def insert_fake_bboxes(can_bboxes, ref_bbox, fake_f64=True, encode_sep_as_ref=True, flavour="MEM-SEP-CAN-BAD"):
+    """encodings.py:97-148.  MEM-SEP-CAN*: [ref|can_i]*P, [ref, ref] (SEP, NON) and, with -BAD, [fake, fake] (SEP, BAD);
+    MEM-CAN-SEP*: [can_i|ref]*P, ...; encode_sep_as_ref=False encodes a separator with its candidate's box.  torch.cat promotes
+    to float64 when the (float64) fake bbox takes part - i.e. only in the -BAD flavours."""
     B, P, _ = can_bboxes.shape
-    fake = distant_fake_bbox(fake_f64).repeat(B, 1, 1)
     parts = []
     for i in range(P):
-        first = ref_bbox if encode_sep_as_ref else can_bboxes[:, [i], :]
-        parts += [first, can_bboxes[:, [i], :]]
-    parts += [ref_bbox, ref_bbox, fake, fake]
+        sep = ref_bbox if encode_sep_as_ref else can_bboxes[:, [i], :]
+        parts += [sep, can_bboxes[:, [i], :]] if "MEM-SEP-CAN" in flavour else [can_bboxes[:, [i], :], sep]
+    parts += [ref_bbox, ref_bbox]
+    if "BAD" in flavour:
+        fake = distant_fake_bbox(fake_f64).repeat(B, 1, 1)
+        parts += [fake, fake]
     return torch.cat(parts, dim=1)
 
 
@@ -113,17 +119,17 @@ def spatial_ids(mem_bboxes, can_bboxes_with_fakes, range_factor=15.0):
     return (mxy + MAX_DIST, msz + MAX_SIZE), (cxy + MAX_DIST, csz + MAX_SIZE)
 
 
-def token_bucket_ids(mem_bboxes, can_bboxes, fake_f64=True):
-    """All three bucket indices per token, token order [MEM*L, (SEP,CAN)*P, SEP,NON, SEP,BAD].
+def token_bucket_ids(mem_bboxes, can_bboxes, fake_f64=True, flavour="MEM-SEP-CAN-BAD", encode_sep_as_ref=True):
+    """All three bucket indices per token, token order [MEM*L, pair*P, pair(NON) [, pair(BAD)]] with pair = (SEP, CAN) or (CAN, SEP).
     Returns int64 [B, T, 3] with columns (xy, size, time)."""
     mem_bboxes = torch.as_tensor(mem_bboxes, dtype=torch.float32)
     can_bboxes = torch.as_tensor(can_bboxes, dtype=torch.float32)
     B, L, _ = mem_bboxes.shape
     P = can_bboxes.shape[1]
     ref = mem_bboxes[:, -1:, :].clone()
-    fakes = insert_fake_bboxes(can_bboxes, ref, fake_f64=fake_f64)
+    fakes = insert_fake_bboxes(can_bboxes, ref, fake_f64=fake_f64, encode_sep_as_ref=encode_sep_as_ref, flavour=flavour)
     (mxy, msz), (cxy, csz) = spatial_ids(mem_bboxes, fakes)
-    mt, ct = temporal_ids(L, P + 2)
+    mt, ct = temporal_ids(L, P + (2 if "BAD" in flavour else 1))
     xy = torch.cat([mxy, cxy], dim=1)
     sz = torch.cat([msz, csz], dim=1)
     t = torch.cat([mt, ct]).repeat(B, 1)

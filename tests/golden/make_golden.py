@@ -145,6 +145,63 @@ def _run_dt_cases(ref_network, cases):
         print("wrote", name, {k: v.shape for k, v in out.items() if k.startswith("logits")})
 
 
+DT_FLAVOUR_CASES = [
+    # name, input_flavour, encode_separator_as_reference, encode_special_tokens, B, L, P, seed   (d = 64, ff = 128)
+    ("sep_can", "MEM-SEP-CAN", True, False, 3, 11, 5, 31),
+    ("can_sep_bad", "MEM-CAN-SEP-BAD", True, False, 3, 11, 5, 32),
+    ("can_sep", "MEM-CAN-SEP", True, False, 4, 6, 16, 33),
+    ("sep_can_bad_sepcan", "MEM-SEP-CAN-BAD", False, False, 3, 11, 5, 34),
+    ("can_sep_bad_sepcan", "MEM-CAN-SEP-BAD", False, False, 3, 4, 7, 35),
+    ("sep_can_sepcan", "MEM-SEP-CAN", False, False, 3, 11, 5, 36),
+]
+
+
+def make_dt_flavours(ref):
+    """The non-shipped token layouts of network.py:103-165 / encodings.py:112-146, from the REFERENCE itself (d = 64).  Also records
+    what the reference does with the CLS-* flavours and with encode_special_tokens (see the notes saved in the file)."""
+    ref_network, _, _ = ref
+    out = {}
+    for name, flavour, sep_ref, enc_special, B, L, P, seed in DT_FLAVOUR_CASES:
+        a = ref_args(64, 128, flavour)
+        a.encode_separator_as_reference = sep_ref
+        a.encode_special_tokens = enc_special
+        model = ref_network.BUSCA(a).eval()
+        sd = synth.dt_state_dict(seed, d=64, ff=128, flavour=flavour)
+        load_dt_weights(model, sd)
+        inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)
+        for mode, f64 in (("f64", True), ("f32", False)):
+            set_fake_dtype(model, f64)
+            r = run_ref_dt(model, inp)
+            for k, v in r.items():
+                out["%s/%s_%s" % (name, k, mode)] = v
+        out[name + "/meta"] = np.array([B, L, P, seed, int(sep_ref), int(enc_special)])
+        out[name + "/flavour"] = np.array(flavour)
+        print("flavour case", name, flavour, r["logits"].shape)
+        del model
+    notes = []
+    # CLS-*: PositionalEncoding._get_temporal_ids (encodings.py:161) replaces the index TENSOR by the int 0, torch.clamp then fails
+    try:
+        a = ref_args(64, 128, "CLS-MEM-SEP-CAN-BAD")
+        model = ref_network.BUSCA(a).eval()
+        run_ref_dt(model, synth.dt_inputs(1, 2, 4, 3))
+        notes.append("CLS-MEM-SEP-CAN-BAD: ran")
+    except Exception as e:  # noqa: BLE001
+        notes.append("CLS-MEM-SEP-CAN-BAD: %s: %s" % (type(e).__name__, str(e)[:160]))
+    # encode_special_tokens with dim_embedding != trans_dim: the tokens get dim_embedding entries and torch.cat fails
+    try:
+        a = ref_args(64, 128, "MEM-SEP-CAN-BAD")
+        a.encode_special_tokens = True
+        model = ref_network.BUSCA(a).eval()
+        run_ref_dt(model, synth.dt_inputs(1, 2, 4, 3))
+        notes.append("encode_special_tokens, E=512 d=64: ran")
+    except Exception as e:  # noqa: BLE001
+        notes.append("encode_special_tokens, E=512 d=64: %s: %s" % (type(e).__name__, str(e)[:160]))
+    out["notes"] = np.array(notes)
+    for n in notes:
+        print("note:", n)
+    np.savez_compressed(os.path.join(OUT, "flavours_dt.npz"), **out)
+
+
 class FakeTrack:
     """Track protocol of associate_embeddings."""
     def __init__(self, tlwh_hist, images, scale=1.0):
@@ -547,6 +604,8 @@ def main():
     ref = import_reference()
     if "dt" in which:
         make_dt(ref)
+    if "dt_flavours" in which:
+        make_dt_flavours(ref)
     if "dt512" in which:
         make_dt512(ref)
     if "assoc512" in which:

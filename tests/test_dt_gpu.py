@@ -177,3 +177,81 @@ def test_two_tracks_per_workgroup_flavour(ctx, shape):
     if B > 256 and d == 256:        # the automatic choice for more than one round of workgroups is the two-track flavour
         auto, _ = _run(ctx, sd, inp, "f16", True)
         assert ctx.get_option("last_dt_ntrk") == 2 and np.array_equal(auto["logits"], two["logits"])
+
+
+# ---- the non-shipped token layouts (network.py:103-165, encodings.py:112-146) ---------------------------------------------------
+def _flavour_file():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "flavours_dt.npz"))
+    return g, sorted({k.split("/")[0] for k in g.files if "/" in k})
+
+
+@pytest.mark.parametrize("mode", ["f64", "f32"])
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("tiled", [0, 1], ids=["fused", "layerwise"])
+def test_token_layout_flavours_vs_reference(ctx, mode, prec, tiled):
+    """MEM-SEP-CAN / MEM-CAN-SEP, with and without the BAD token, separators encoded as the reference box or as their candidate's:
+    both kernel paths against outputs of the reference itself (tests/golden/make_golden.py dt_flavours), bucket indices bit-exact
+    against the oracle."""
+    from busca_amd.dt import DecisionTransformerHIP
+    from oracle import encoding as oenc
+    g, names = _flavour_file()
+    tol = TOL[prec]
+    ctx.set_option("dt_tiled", tiled)
+    try:
+        for name in names:
+            B, L, P, seed, sep_ref, _ = (int(v) for v in g[name + "/meta"])
+            flavour = str(g[name + "/flavour"])
+            sd = synth.dt_state_dict(seed, d=64, ff=128, flavour=flavour)
+            inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)
+            m = DecisionTransformerHIP(ctx, sd, activation="relu", fake_bbox_f64=(mode == "f64"), precision=prec, input_flavour=flavour,
+                                       encode_separator_as_reference=bool(sep_ref))
+            out = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"], want_hidden=True, want_att=True)
+            torch.cuda.synchronize()
+            out = {k: v.cpu().numpy() for k, v in out.items()}
+            n = P + (2 if "BAD" in flavour else 1)
+            assert out["logits"].shape == (B, n) and out["hidden"].shape == (B, L + 2 * n, 64), name
+            assert np.abs(out["logits"] - g[name + "/logits_" + mode]).max() <= tol["logit"], name
+            assert np.abs(out["probs"] - g[name + "/probs_" + mode]).max() <= tol["prob"], name
+            pos = m.can_positions(L, P)
+            assert np.abs(out["hidden"][:, pos] - g[name + "/can_hidden_" + mode]).max() <= tol["hidden"], name
+            assert np.abs(out["hidden"][:, :L].mean(1) - g[name + "/mem_hidden_mean_" + mode]).max() <= tol["hidden"], name
+            assert np.abs(out["att"] - g[name + "/att_" + mode]).max() <= tol["att"], name
+            ref_p = g[name + "/probs_" + mode]
+            srt = np.sort(ref_p, axis=-1)
+            clear = (srt[:, -1] - srt[:, -2]) > tol["margin"]
+            assert (out["argmax"][clear] == g[name + "/argmax_" + mode][clear]).all(), name
+            assert (out["argmax"] == out["probs"].argmax(-1)).all(), name
+            ids = m.bucket_ids(inp["mem_boxes"], inp["can_boxes"]).cpu().numpy()
+            want = oenc.token_bucket_ids(inp["mem_boxes"], inp["can_boxes"], fake_f64=(mode == "f64"), flavour=flavour,
+                                         encode_sep_as_ref=bool(sep_ref)).numpy()
+            assert np.array_equal(ids, want), name
+    finally:
+        ctx.set_option("dt_tiled", 0)
+
+
+def test_busca_accepts_the_reference_flavour_options():
+    """busca_amd.network.BUSCA takes every input flavour the reference can run (and encode_special_tokens when it is a no-op),
+    and refuses the ones the reference itself fails on with the reference's kind of error."""
+    import types
+    from busca_amd.network import BUSCA
+
+    def args(**kw):
+        a = types.SimpleNamespace(num_layer=4, nhead=4, dim_embedding=512, trans_dim=64, ff_size=128, activation="gelu", dropout_p=0.1,
+                                  input_flavour="MEM-SEP-CAN-BAD", output_flavour="CAN", encode_separator_as_reference=True,
+                                  encode_special_tokens=False, reid_weights_file="no", device=torch.device("cuda:0"), precision="f32")
+        a.__dict__.update(kw)
+        return a
+    for fl, nspec in (("MEM-SEP-CAN", 1), ("MEM-CAN-SEP-BAD", 2), ("MEM-CAN-SEP", 1)):
+        m = BUSCA(args(input_flavour=fl, encode_separator_as_reference=False)).to(torch.device("cuda:0")).eval()
+        mem = torch.zeros(2, 3, 3, 384, 128)
+        can = torch.zeros(2, 4, 3, 384, 128)
+        mb = torch.tensor([[[10., 10, 60, 110]] * 3] * 2)
+        cb = torch.tensor([[[12., 11, 63, 115]] * 4] * 2)
+        logits = m.forward(mem, can, memory_bboxes=mb, candidates_bboxes=cb, return_logits=True)
+        assert tuple(logits.shape) == (2, 4 + nspec) and tuple(m.logits.shape) == (2, 4 + nspec, 64)
+        assert ("bad_token" in m.state_dict()) == (nspec == 2)
+    with pytest.raises(NotImplementedError):
+        BUSCA(args(input_flavour="CLS-MEM-SEP-CAN-BAD"))
+    with pytest.raises(RuntimeError):
+        BUSCA(args(encode_special_tokens=True))                      # dim_embedding 512 != trans_dim 64: torch.cat fails in the reference
+    BUSCA(args(encode_special_tokens=True, trans_dim=512, ff_size=1024))   # same widths: the option changes nothing

@@ -38,6 +38,44 @@ def test_dt_forward_matches_reference(path, mode):
     assert (o["argmax"].numpy()[clear] == g["argmax_" + mode][clear]).all()
 
 
+def _flavour_cases():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "flavours_dt.npz"))
+    return g, sorted({k.split("/")[0] for k in g.files if "/" in k})
+
+
+@pytest.mark.parametrize("mode", ["f64", "f32"])
+def test_dt_token_layout_flavours_match_reference(mode):
+    """MEM-SEP-CAN / MEM-CAN-SEP, with and without BAD, separators encoded as the reference box or as their candidate's
+    (network.py:103-165, encodings.py:112-146): the oracle against outputs of the reference itself."""
+    g, names = _flavour_cases()
+    assert len(names) >= 6
+    for name in names:
+        B, L, P, seed, sep_ref, _ = (int(v) for v in g[name + "/meta"])
+        flavour = str(g[name + "/flavour"])
+        sd = synth.dt_state_dict(seed, d=64, ff=128, flavour=flavour)
+        inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)
+        # without a BAD token no float64 box takes part in the reference's torch.cat: the candidate side stays float32
+        cfg = odt.DTConfig(d=64, ff=128, fake_f64=(mode == "f64"), flavour=flavour, encode_sep_as_ref=bool(sep_ref))
+        o = odt.dt_forward(sd, cfg, **inp, return_all=True)
+        n = P + (2 if "BAD" in flavour else 1)
+        assert o["logits"].shape == (B, n)
+        np.testing.assert_allclose(o["logits"].numpy(), g[name + "/logits_" + mode], rtol=0, atol=2e-5, err_msg=name)
+        np.testing.assert_allclose(o["probs"].numpy(), g[name + "/probs_" + mode], rtol=0, atol=2e-6, err_msg=name)
+        pos = odt.can_positions(L, P, flavour)
+        np.testing.assert_allclose(o["hidden"][:, pos].numpy(), g[name + "/can_hidden_" + mode], rtol=0, atol=5e-5, err_msg=name)
+        np.testing.assert_allclose(o["hidden"][:, :L].mean(1).numpy(), g[name + "/mem_hidden_mean_" + mode], rtol=0, atol=5e-5, err_msg=name)
+        att = np.stack([a.numpy() for a in o["att"]])
+        np.testing.assert_allclose(att, g[name + "/att_" + mode], rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_reference_rejects_cls_flavours_and_mismatched_special_tokens():
+    """What the reference itself does with the options this library refuses (recorded by tests/golden/make_golden.py dt_flavours)."""
+    g, _ = _flavour_cases()
+    notes = [str(n) for n in g["notes"]]
+    assert any(n.startswith("CLS-MEM-SEP-CAN-BAD: TypeError") for n in notes), notes          # encodings.py:161
+    assert any(n.startswith("encode_special_tokens, E=512 d=64: RuntimeError") for n in notes), notes   # network.py:128-130
+
+
 def test_activation_quirk_is_relu():
     """The reference's cloned layers run ReLU although the YAML says gelu (custom_layers.py:24-27,44-45)."""
     g = np.load(DT_SETS[0])
