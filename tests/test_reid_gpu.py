@@ -254,6 +254,29 @@ def test_reid_halo_conv_path(ctx, monkeypatch):
     ReIDEncoderHIP(ctx, sd)
 
 
+def test_reid_halo_two_by_two_waves_path(ctx, monkeypatch):
+    """Layer 1's 3x3 at very large batches: 2 x 2 waves on 256-pixel tiles, two partial-sum rows per tile (conv3x3_halo_kernel
+    <2, 32, 8, 2>; automatic from 5120 tiles on, forced here at a batch the suite can afford).  A wave's half tile is exactly one
+    128-pixel tile of the one-tile-wide kernel and both accumulate K in the same order, so plain and weighted features must be
+    BIT-IDENTICAL to that kernel's."""
+    from busca_amd.reid import ReIDEncoderHIP
+    sd = synth.reid_state_dict(3)
+    n = 112
+    crops = _crops(901, n)
+    wts = (1 + (np.arange(n) % 5)).astype(np.float32)
+    monkeypatch.setenv("BUSCA_REID_HALO_WPX", "0")
+    m0 = ReIDEncoderHIP(ctx, sd)
+    narrow, narrow_w = m0.forward(crops).cpu().numpy(), m0.forward(crops, weights=wts).cpu().numpy()
+    monkeypatch.setenv("BUSCA_REID_HALO_WPX", "1")
+    monkeypatch.setenv("BUSCA_REID_HALO_WPX_MIN", "1")
+    m = ReIDEncoderHIP(ctx, sd)
+    wide, wide_w = m.forward(crops).cpu().numpy(), m.forward(crops, weights=wts).cpu().numpy()
+    assert np.isfinite(wide).all() and np.array_equal(wide, narrow) and np.array_equal(wide_w, narrow_w)
+    monkeypatch.delenv("BUSCA_REID_HALO_WPX")
+    monkeypatch.delenv("BUSCA_REID_HALO_WPX_MIN")
+    ReIDEncoderHIP(ctx, sd)
+
+
 @pytest.mark.parametrize("n,nw,pt", [(5, 0, 0), (8, 16, 2), (8, 8, 4), (24, 4, 4), (24, 8, 2), (40, 4, 2)])
 def test_reid_kwave_conv_path(ctx, monkeypatch, n, nw, pt):
     """Small / mid batches run most convs through conv_kwave_kernel (K split across the waves of a workgroup,
