@@ -230,8 +230,11 @@ struct TimedLaunch {   // RAII: records start/stop events around one kernel laun
 static bool dt_cfg_ok(const busca_dt_cfg* g) {
     if (!g) return false;
     if (!(g->d == 64 || g->d == 256 || g->d == 512)) return false;
-    if (g->nhead != 4 || g->nlayers < 1 || g->nlayers > DT_MAX_LAYERS) return false;
-    if (g->E != 512 || g->ff != 2 * g->d) return false;
+    if (g->nlayers < 1 || g->nlayers > DT_MAX_LAYERS) return false;
+    if (g->nhead < 1 || g->d % g->nhead != 0) return false;
+    const int hd = g->d / g->nhead;
+    if (!(hd == 16 || hd == 32 || hd == 64 || hd == 128)) return false;             // head widths the attention kernels are built for
+    if (g->E != 512 || g->ff < g->d || g->ff % g->d != 0 || g->ff > 8 * g->d) return false;   // ff = k d: whole column blocks of the layer-wise GEMM
     if (g->precision != BUSCA_PREC_F32 && g->precision != BUSCA_PREC_F16) return false;
     if (g->layout & ~(BUSCA_LAYOUT_CAN_FIRST | BUSCA_LAYOUT_NO_BAD | BUSCA_LAYOUT_SEP_AS_CAN)) return false;
     return true;
@@ -272,7 +275,7 @@ static size_t pack_matrix(const float* W, int N, int K, int prec, unsigned char*
 extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const float* blob, size_t blob_floats,
                                      const uint16_t* lut_xy, const uint16_t* lut_sz, const uint16_t* lut_t, int32_t lut_c) {
     if (!c) return BUSCA_EINVAL;
-    if (!dt_cfg_ok(g)) return fail(c, BUSCA_EINVAL, "unsupported DT config (d in {64,256,512}, ff == 2d, nhead == 4, E == 512)");
+    if (!dt_cfg_ok(g)) return fail(c, BUSCA_EINVAL, "unsupported DT config (d in {64,256,512}, d / nhead in {16,32,64,128}, ff = k d with k <= 8, E == 512)");
     if (!blob || blob_floats != busca_dt_blob_floats(g)) return fail(c, BUSCA_EINVAL, "weight blob has %zu floats, expected %zu", blob_floats, busca_dt_blob_floats(g));
     if (!lut_xy || !lut_sz || !lut_t || lut_c <= 0 || 3 * lut_c < g->d) return fail(c, BUSCA_EINVAL, "bad encoding LUTs");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -460,39 +463,51 @@ static bool dtl_gemm_glds(busca_ctx* c, hipStream_t s, const DTLArgs& a, int N, 
     return true;
 }
 
-template <int PREC, int D, int MT>
-static int dtl_attention(busca_ctx* c, hipStream_t s, const void* qkv, void* O, int B, int T, float* att) {
-    constexpr int ES = Prec<PREC>::ES, HD = D / 4, TPK = Prec<PREC>::CHUNK * Prec<PREC>::nchunks(MT);
+template <int PREC, int HD, int MT>
+static int dtl_attention(busca_ctx* c, hipStream_t s, const void* qkv, void* O, int B, int T, int D, int NH, float* att) {
+    constexpr int ES = Prec<PREC>::ES, TPK = Prec<PREC>::CHUNK * Prec<PREC>::nchunks(MT);
     const size_t lds = (size_t)16 * MT * (HD * ES + 16) + (size_t)HD * (TPK * ES + 16);
     if (lds > 160 * 1024) return fail(c, BUSCA_EINVAL, "tiled attention: %d tokens x head dim %d do not fit the LDS in this precision", T, HD);
-    auto kern = dtl_attention_kernel<PREC, D, MT>;
+    auto kern = dtl_attention_kernel<PREC, HD, MT>;
     { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
     TimedLaunch tl(c, s);
-    hipLaunchKernelGGL(kern, dim3(B, 4), dim3(256), lds, s, qkv, O, T, att);
+    hipLaunchKernelGGL(kern, dim3(B, NH), dim3(256), lds, s, qkv, O, T, D, NH, att);
     return BUSCA_OK;
 }
 
-template <int PREC, int D>
-static int dtl_attention_mt(busca_ctx* c, hipStream_t s, int MT, const void* qkv, void* O, int B, int T, float* att) {
+template <int PREC, int HD>
+static int dtl_attention_mt(busca_ctx* c, hipStream_t s, int MT, const void* qkv, void* O, int B, int T, int D, int NH, float* att) {
     switch (MT) {
-        case 1: return dtl_attention<PREC, D, 1>(c, s, qkv, O, B, T, att);
-        case 2: return dtl_attention<PREC, D, 2>(c, s, qkv, O, B, T, att);
-        case 3: return dtl_attention<PREC, D, 3>(c, s, qkv, O, B, T, att);
-        case 4: return dtl_attention<PREC, D, 4>(c, s, qkv, O, B, T, att);
-        case 5: return dtl_attention<PREC, D, 5>(c, s, qkv, O, B, T, att);
-        case 6: return dtl_attention<PREC, D, 6>(c, s, qkv, O, B, T, att);
-        case 7: return dtl_attention<PREC, D, 7>(c, s, qkv, O, B, T, att);
-        case 8: return dtl_attention<PREC, D, 8>(c, s, qkv, O, B, T, att);
-        case 9: return dtl_attention<PREC, D, 9>(c, s, qkv, O, B, T, att);
+        case 1: return dtl_attention<PREC, HD, 1>(c, s, qkv, O, B, T, D, NH, att);
+        case 2: return dtl_attention<PREC, HD, 2>(c, s, qkv, O, B, T, D, NH, att);
+        case 3: return dtl_attention<PREC, HD, 3>(c, s, qkv, O, B, T, D, NH, att);
+        case 4: return dtl_attention<PREC, HD, 4>(c, s, qkv, O, B, T, D, NH, att);
+        case 5: return dtl_attention<PREC, HD, 5>(c, s, qkv, O, B, T, D, NH, att);
+        case 6: return dtl_attention<PREC, HD, 6>(c, s, qkv, O, B, T, D, NH, att);
+        case 7: return dtl_attention<PREC, HD, 7>(c, s, qkv, O, B, T, D, NH, att);
+        case 8: return dtl_attention<PREC, HD, 8>(c, s, qkv, O, B, T, D, NH, att);
+        case 9: return dtl_attention<PREC, HD, 9>(c, s, qkv, O, B, T, D, NH, att);
     }
     return fail(c, BUSCA_EINVAL, "tiled attention supports at most 144 tokens per track (got %d)", T);
 }
 
+// head width HD = d / nhead in {16, 32, 64, 128} (nhead 4 at d = 64 / 256 / 512 are 16 / 64 / 128)
+template <int PREC>
+static int dtl_attention_hd(busca_ctx* c, hipStream_t s, int MT, const void* qkv, void* O, int B, int T, int D, int NH, float* att) {
+    switch (D / NH) {
+        case 16: return dtl_attention_mt<PREC, 16>(c, s, MT, qkv, O, B, T, D, NH, att);
+        case 32: return dtl_attention_mt<PREC, 32>(c, s, MT, qkv, O, B, T, D, NH, att);
+        case 64: return dtl_attention_mt<PREC, 64>(c, s, MT, qkv, O, B, T, D, NH, att);
+        case 128: return dtl_attention_mt<PREC, 128>(c, s, MT, qkv, O, B, T, D, NH, att);
+    }
+    return fail(c, BUSCA_EINVAL, "tiled attention: head width %d not built (16, 32, 64, 128)", D / NH);
+}
+
 // Workspace of the layer-wise path for M rows (bytes).  Grown outside the forward by busca_dt_reserve; a forward that finds
 // it too small grows it itself (one stream synchronisation + hipMalloc, first call of a larger shape only).
-static size_t dtl_ws_bytes(size_t M, int D, size_t es) {
+static size_t dtl_ws_bytes(size_t M, int D, int FF, size_t es) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return al(M * D * 4) + al(M * D * 2) + al(M * 3 * D * es) + al(M * D * es) + al(M * 2 * D * es) + al(M * 3 * 4);
+    return al(M * D * 4) + al(M * D * 2) + al(M * 3 * D * es) + al(M * D * es) + al(M * FF * es) + al(M * 3 * 4);
 }
 
 static int dtl_ws_ensure(busca_ctx* c, size_t need, hipStream_t s) {
@@ -508,13 +523,13 @@ template <int PREC, int D>
 static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     DTState& S = c->dt;
     constexpr size_t ES = Prec<PREC>::ES;
-    const int T = K.T, B = K.B, L = K.L, P = K.P, FF = 2 * D, E = 512;
+    const int T = K.T, B = K.B, L = K.L, P = K.P, FF = S.cfg.ff, NH = S.cfg.nhead, E = 512;
     const int MT = (T + 15) / 16;
     if (MT > 9) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most 144 tokens per track (T=%d)", T);
     if (P + K.nspec > 128) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most %d proposals (P=%d)", 128 - K.nspec, P);
     const size_t M = (size_t)B * T;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    { int rc = dtl_ws_ensure(c, dtl_ws_bytes(M, D, ES), s); if (rc) return rc; }
+    { int rc = dtl_ws_ensure(c, dtl_ws_bytes(M, D, FF, ES), s); if (rc) return rc; }
     char* p = (char*)S.ws;
     float* X = (float*)p; p += al(M * D * 4);
     _Float16* Xh = (_Float16*)p; p += al(M * D * 2);
@@ -526,7 +541,7 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     hipLaunchKernelGGL(dt_bucket_ids_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, K.mem_ltrb, K.can_ltrb, B, L, P, K.fake_f64, K.can_pos, K.nspec, K.sep_can, ids);
     DTLArgs a{};
     a.M = (int)M; a.L = L; a.P = P; a.T = T; a.E = E; a.can_pos = K.can_pos; a.X = X; a.Xh = Xh; a.act = K.act;
-    a.qscale = 1.0f / sqrtf((float)(D / 4));
+    a.qscale = 1.0f / sqrtf((float)(D / NH));
     // embed + assembly + encoding
     a.W = S.tw.w_embed; a.K = E; a.bias = K.b_embed; a.mem_feat = K.mem_feat; a.can_feat = K.can_feat; a.ids = ids;
     a.lut_xy = K.lut_xy; a.lut_sz = K.lut_sz; a.lut_t = K.lut_t; a.lut_c = K.lut_c;
@@ -540,8 +555,8 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
             if (!(PREC == 1 && dtl_gemm_glds<GEMM_EPI_BIAS_QSCALE>(c, s, a, 3 * D, D, &rc))) rc = dtl_gemm<PREC, D, DTL_EPI_QKV>(c, s, a, 3);
             if (rc) return rc;
         }
-        float* att = K.att ? K.att + (size_t)l * B * 4 * T * T : nullptr;
-        { int rc = dtl_attention_mt<PREC, D>(c, s, MT, QKV, O, B, T, att); if (rc) return rc; }
+        float* att = K.att ? K.att + (size_t)l * B * NH * T * T : nullptr;
+        { int rc = dtl_attention_hd<PREC>(c, s, MT, QKV, O, B, T, D, NH, att); if (rc) return rc; }
         a.A = O; a.lda = D; a.W = S.tw.w_out[l]; a.K = D; a.bias = W.b_out; a.gamma = W.g1; a.beta = W.be1;
         { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
         a.A = Xop; a.lda = D; a.W = S.tw.w1[l]; a.K = D; a.bias = W.b1; a.out16 = H; a.ldo = FF;
@@ -565,7 +580,7 @@ extern "C" int busca_dt_reserve(busca_ctx* c, int32_t B, int32_t L, int32_t P, v
     if (!c->dt.loaded) return fail(c, BUSCA_ENOWEIGHTS, "busca_dt_reserve before busca_dt_load_weights");
     if (B < 0 || L < 1 || P < 1) return fail(c, BUSCA_EINVAL, "bad shape B=%d L=%d P=%d", B, L, P);
     const size_t es = c->dt.cfg.precision == BUSCA_PREC_F32 ? 4 : 2;
-    return dtl_ws_ensure(c, dtl_ws_bytes((size_t)B * (L + 2 * (P + c->dt.proto.nspec)), c->dt.cfg.d, es), (hipStream_t)stream);
+    return dtl_ws_ensure(c, dtl_ws_bytes((size_t)B * (L + 2 * (P + c->dt.proto.nspec)), c->dt.cfg.d, c->dt.cfg.ff, es), (hipStream_t)stream);
 }
 
 extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
@@ -584,7 +599,8 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     const int d = c->dt.cfg.d, prec = c->dt.cfg.precision;
     hipStream_t s = (hipStream_t)stream;
     const bool force_tiled = c->opt.dt_tiled != 0;          // testing: run the layer-wise path on any shape
-    const bool fused_ok = !force_tiled && P + K.nspec <= 64;
+    // the one-kernel path is built for the shipped geometry (four heads, ff = 2 d); other head counts / widths run layer-wise
+    const bool fused_ok = !force_tiled && P + K.nspec <= 64 && c->dt.cfg.nhead == 4 && c->dt.cfg.ff == 2 * c->dt.cfg.d;
     // f16: the fused kernel is bound by its weight stream, so from two rounds of workgroups on (B > 256 CUs) every workgroup
     // takes TWO tracks and each streamed weight fragment feeds twice the tokens (BUSCA_DT_NTRK=1/2 forces either)
     const int ntrk_env = c->opt.dt_ntrk;

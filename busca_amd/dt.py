@@ -26,7 +26,7 @@ def layout_bits(input_flavour, encode_separator_as_reference=True):
 
 class DecisionTransformerHIP:
     def __init__(self, ctx, state_dict, activation="relu", fake_bbox_f64=True, precision="f32", input_flavour="MEM-SEP-CAN-BAD",
-                 encode_separator_as_reference=True):
+                 encode_separator_as_reference=True, nhead=4):
         self.ctx = ctx
         self.input_flavour = input_flavour
         self.nspec = 2 if "BAD" in input_flavour else 1        # appended candidates: NON [, BAD]
@@ -35,14 +35,15 @@ class DecisionTransformerHIP:
         # 127-140): no BAD token, no promotion
         fake_bbox_f64 = bool(fake_bbox_f64) and self.nspec == 2
         d, ff, nl, E = weights.dt_dims(state_dict)
-        self.d, self.ff, self.nlayers, self.E, self.nhead = d, ff, nl, E, 4
+        self.d, self.ff, self.nlayers, self.E, self.nhead = d, ff, nl, E, int(nhead)    # (nhead is not in the state_dict: in_proj is [3d, d] whatever it is)
         self.precision = precision
-        self.cfg = _lib.DTCfg(d, ff, 4, nl, E, _ACT[activation], 1 if fake_bbox_f64 else 0, _PREC[precision],
+        self.cfg = _lib.DTCfg(d, ff, self.nhead, nl, E, _ACT[activation], 1 if fake_bbox_f64 else 0, _PREC[precision],
                               layout_bits(input_flavour, encode_separator_as_reference))
         self._blob = weights.dt_blob(state_dict, nl)
         want = ctx.lib.busca_dt_blob_floats(C.byref(self.cfg))
         if want == 0:
-            raise _lib.BuscaError("unsupported Decision-Transformer shape d=%d ff=%d layers=%d E=%d" % (d, ff, nl, E))
+            raise _lib.BuscaError("unsupported Decision-Transformer shape d=%d ff=%d nhead=%d layers=%d E=%d (built: d in 64/256/512, "
+                                  "d/nhead in 16/32/64/128, ff a multiple of d up to 8 d, E = 512)" % (d, ff, self.nhead, nl, E))
         assert self._blob.size == want, (self._blob.size, want)
         self._luts = weights.encoding_luts(d)
         self._upload()
@@ -67,7 +68,7 @@ class DecisionTransformerHIP:
         return t.to(device=dev, dtype=torch.float32).contiguous()
 
     def forward(self, mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=False, want_att=False, stream=None):
-        """-> dict(logits[B,P+2], probs[B,P+2], argmax[B] int32, hidden?[B,T,d], att?[nl,B,4,T,T]); P+1 columns without the BAD token."""
+        """-> dict(logits[B,P+2], probs[B,P+2], argmax[B] int32, hidden?[B,T,d], att?[nl,B,nhead,T,T]); P+1 columns without the BAD token."""
         self._ensure_loaded()
         dev = torch.device("cuda", self.ctx.device)
         mem_feat, can_feat = self._f32(mem_feat, dev), self._f32(can_feat, dev)
@@ -82,7 +83,7 @@ class DecisionTransformerHIP:
         if want_hidden:
             out["hidden"] = torch.empty(B, T, self.d, device=dev)
         if want_att:
-            out["att"] = torch.empty(self.nlayers, B, 4, T, T, device=dev)
+            out["att"] = torch.empty(self.nlayers, B, self.nhead, T, T, device=dev)
         s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         self.ctx.check(self.ctx.lib.busca_dt_forward(
             self.ctx.h, mem_feat.data_ptr(), can_feat.data_ptr(), mem_ltrb.data_ptr(), can_ltrb.data_ptr(), B, L, P,

@@ -76,8 +76,13 @@ class BUSCA:
             # the learned tokens then have dim_embedding entries and are concatenated, unencoded, with trans_dim-wide rows
             # (network.py:52-69,128-130): torch.cat raises in the reference
             raise RuntimeError("Sizes of tensors must match except in dimension 1: encode_special_tokens needs dim_embedding == trans_dim")
-        if args.nhead != 4 or args.dim_embedding != 512:
-            raise NotImplementedError("nhead must be 4 and dim_embedding 512 (all shipped configs)")
+        d, nh, ff = int(args.trans_dim), int(args.nhead), int(args.ff_size)
+        if args.dim_embedding != 512:
+            raise NotImplementedError("dim_embedding must be 512 (the ReID feature, all shipped configs)")
+        if d not in (64, 256, 512) or nh < 1 or d % nh or d // nh not in (16, 32, 64, 128) or ff < d or ff % d or ff > 8 * d:
+            raise NotImplementedError("built: trans_dim in {64, 256, 512}, trans_dim / nhead in {16, 32, 64, 128}, ff_size a multiple of "
+                                      "trans_dim up to 8x (nhead 4 with ff_size = 2 trans_dim - every shipped config - runs as one kernel, "
+                                      "the others layer-wise)")
         # The reference's cloned encoder layers run ReLU whatever `activation` says (deepcopy +
         # TransformerEncoderLayer.__setstate__, custom_layers.py:24-27,44-45).  Set
         # args.fix_activation_quirk = True to run the configured activation instead (gelu only).
@@ -223,7 +228,7 @@ class BUSCA:
             dt_sd = {k: v for k, v in self._sd.items() if not k.startswith(_REID_PREFIX)}
             self._dt = DecisionTransformerHIP(self._ctx, dt_sd, activation=self.effective_activation,
                                               fake_bbox_f64=self.pinned_numpy, precision=self.precision,
-                                              input_flavour=self.args.input_flavour,
+                                              input_flavour=self.args.input_flavour, nhead=int(self.args.nhead),
                                               encode_separator_as_reference=bool(self.args.encode_separator_as_reference))
             self._reid = ReIDEncoderHIP(self._ctx, self._sd, prefix=_REID_PREFIX, precision=self.reid_precision)
             self._dirty = False

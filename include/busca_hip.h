@@ -58,8 +58,9 @@ int busca_get_option(busca_ctx* ctx, const char* name, int32_t* value);
 /* ---- Decision Transformer (busca/network.py:176-244 without the ReID stage) ----------------- */
 typedef struct {
     int32_t d;             /* trans_dim (network.py:17); 64, 256 or 512 */
-    int32_t ff;            /* ff_size */
-    int32_t nhead;         /* must be 4 (config/ **.yml:3) */
+    int32_t ff;            /* ff_size: a multiple of d, at most 8 d (2 d in every shipped config) */
+    int32_t nhead;         /* d / nhead in {16, 32, 64, 128} (4 in every shipped config, config/ **.yml:3).  nhead = 4 with ff = 2 d runs as
+                              ONE kernel when the tokens fit on chip; every other geometry runs layer-wise (same arithmetic type) */
     int32_t nlayers;       /* num_layer, <= 8 */
     int32_t E;             /* dim_embedding of the ReID feature (512) */
     int32_t activation;    /* BUSCA_ACT_*; the reference effectively runs RELU */

@@ -202,6 +202,37 @@ def make_dt_flavours(ref):
     np.savez_compressed(os.path.join(OUT, "flavours_dt.npz"), **out)
 
 
+DT_GEOMETRY_CASES = [
+    # name, d, ff, nhead, B, L, P, seed : head counts / feed-forward widths other than the shipped nhead = 4, ff = 2 d
+    ("d64_h2_ff256", 64, 256, 2, 3, 11, 5, 41),
+    ("d64_h4_ff64", 64, 64, 4, 3, 6, 16, 42),
+    ("d256_h8_ff256", 256, 256, 8, 2, 11, 5, 43),
+    ("d256_h2_ff1024", 256, 1024, 2, 2, 5, 7, 44),
+    ("d256_h16_ff512", 256, 512, 16, 2, 11, 5, 45),
+]
+
+
+def make_dt_geometry(ref):
+    """network.py:84-86 builds the encoder from args.nhead / args.ff_size: cases the one-kernel path is not built for."""
+    ref_network, _, _ = ref
+    out = {}
+    for name, d, ff, nhead, B, L, P, seed in DT_GEOMETRY_CASES:
+        a = ref_args(d, ff)
+        a.nhead = nhead
+        model = ref_network.BUSCA(a).eval()
+        sd = synth.dt_state_dict(seed, d=d, ff=ff)
+        load_dt_weights(model, sd)
+        inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)
+        set_fake_dtype(model, True)
+        r = run_ref_dt(model, inp)
+        for k, v in r.items():
+            out["%s/%s" % (name, k)] = v
+        out[name + "/meta"] = np.array([d, ff, nhead, B, L, P, seed])
+        print("geometry case", name, r["logits"].shape, r["att"].shape)
+        del model
+    np.savez_compressed(os.path.join(OUT, "geometry_dt.npz"), **out)
+
+
 class FakeTrack:
     """Track protocol of associate_embeddings."""
     def __init__(self, tlwh_hist, images, scale=1.0):
@@ -604,6 +635,8 @@ def main():
     ref = import_reference()
     if "dt" in which:
         make_dt(ref)
+    if "dt_geometry" in which:
+        make_dt_geometry(ref)
     if "dt_flavours" in which:
         make_dt_flavours(ref)
     if "dt512" in which:

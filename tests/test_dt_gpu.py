@@ -255,3 +255,32 @@ def test_busca_accepts_the_reference_flavour_options():
     with pytest.raises(RuntimeError):
         BUSCA(args(encode_special_tokens=True))                      # dim_embedding 512 != trans_dim 64: torch.cat fails in the reference
     BUSCA(args(encode_special_tokens=True, trans_dim=512, ff_size=1024))   # same widths: the option changes nothing
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_other_head_counts_and_ff_widths_vs_reference(ctx, prec):
+    """nhead / ff_size other than the shipped 4 / 2 d run layer-wise (head widths 16 / 32 / 64 / 128, ff = k d): against outputs
+    of the reference itself (tests/golden/make_golden.py dt_geometry)."""
+    from busca_amd.dt import DecisionTransformerHIP
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "geometry_dt.npz"))
+    names = sorted({k.split("/")[0] for k in g.files if "/" in k})
+    tol = TOL[prec]
+    for name in names:
+        d, ff, nhead, B, L, P, seed = (int(v) for v in g[name + "/meta"])
+        sd = synth.dt_state_dict(seed, d=d, ff=ff)
+        inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)
+        m = DecisionTransformerHIP(ctx, sd, activation="relu", fake_bbox_f64=True, precision=prec, nhead=nhead)
+        out = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"], want_hidden=True, want_att=True)
+        torch.cuda.synchronize()
+        out = {k: v.cpu().numpy() for k, v in out.items()}
+        assert out["att"].shape == g[name + "/att"].shape, name
+        assert np.abs(out["logits"] - g[name + "/logits"]).max() <= tol["logit"], name
+        assert np.abs(out["probs"] - g[name + "/probs"]).max() <= tol["prob"], name
+        assert np.abs(out["att"] - g[name + "/att"]).max() <= tol["att"], name
+        pos = m.can_positions(L, P)
+        assert np.abs(out["hidden"][:, pos] - g[name + "/can_hidden"]).max() <= tol["hidden"], name
+        srt = np.sort(g[name + "/probs"], axis=-1)
+        clear = (srt[:, -1] - srt[:, -2]) > tol["margin"]
+        assert (out["argmax"][clear] == g[name + "/argmax"][clear]).all(), name
+    with pytest.raises(Exception):
+        DecisionTransformerHIP(ctx, synth.dt_state_dict(1, d=64, ff=128), nhead=8)     # head width 8: not built

@@ -68,6 +68,27 @@ def test_dt_token_layout_flavours_match_reference(mode):
         np.testing.assert_allclose(att, g[name + "/att_" + mode], rtol=0, atol=2e-6, err_msg=name)
 
 
+def _geometry_cases():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "geometry_dt.npz"))
+    return g, sorted({k.split("/")[0] for k in g.files if "/" in k})
+
+
+def test_dt_other_head_counts_and_ff_widths_match_reference():
+    """nhead and ff_size other than the shipped 4 / 2 d (network.py:84-86): the oracle against outputs of the reference itself."""
+    g, names = _geometry_cases()
+    assert len(names) >= 5
+    for name in names:
+        d, ff, nhead, B, L, P, seed = (int(v) for v in g[name + "/meta"])
+        sd = synth.dt_state_dict(seed, d=d, ff=ff)
+        inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)
+        o = odt.dt_forward(sd, odt.DTConfig(d=d, ff=ff, nhead=nhead), **inp, return_all=True)
+        np.testing.assert_allclose(o["logits"].numpy(), g[name + "/logits"], rtol=0, atol=2e-5, err_msg=name)
+        np.testing.assert_allclose(o["probs"].numpy(), g[name + "/probs"], rtol=0, atol=2e-6, err_msg=name)
+        att = np.stack([a.numpy() for a in o["att"]])
+        assert att.shape[2] == nhead
+        np.testing.assert_allclose(att, g[name + "/att"], rtol=0, atol=2e-6, err_msg=name)
+
+
 def test_reference_rejects_cls_flavours_and_mismatched_special_tokens():
     """What the reference itself does with the options this library refuses (recorded by tests/golden/make_golden.py dt_flavours)."""
     g, _ = _flavour_cases()
