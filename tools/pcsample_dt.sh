@@ -1,5 +1,7 @@
 #!/bin/bash
 # PC sampling of the fused Decision-Transformer kernel (gpurun box). Usage: tools/pcsample_dt.sh <outdir> <method: stochastic|host_trap> [B=256] [prec=f16]
+# Round 3: both methods answer "Given PC sampling configuration is not supported on any of the agents" for the unprivileged user of this pool;
+# kept for a box where it is allowed.
 export TMPDIR=/tmp
 OUT=$1; M=${2:-stochastic}; B=${3:-256}; PR=${4:-f16}
 mkdir -p $OUT
