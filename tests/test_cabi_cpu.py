@@ -30,13 +30,24 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_blob_sizes_and_version(lib):
     from busca_amd import _lib, synth, weights
-    assert lib.busca_version() >= 1000
+    assert lib.busca_version() >= 1001             # 1001: busca_dt_cfg.layout
     for d in (64, 256, 512):
         cfg = _lib.DTCfg(d, 2 * d, 4, 4, 512, 0, 1, 0)
         blob = weights.dt_blob(synth.dt_state_dict(1, d=d, ff=2 * d), 4)
         assert lib.busca_dt_blob_floats(ctypes.byref(cfg)) == blob.size
     bad = _lib.DTCfg(100, 200, 4, 4, 512, 0, 1, 0)
     assert lib.busca_dt_blob_floats(ctypes.byref(bad)) == 0
+    # model options beyond the shipped geometry: accepted / refused exactly as include/busca_hip.h says
+    def floats(d, ff, nhead, layout=0):
+        return lib.busca_dt_blob_floats(ctypes.byref(_lib.DTCfg(d, ff, nhead, 4, 512, 0, 1, 0, layout)))
+    assert floats(256, 1024, 8) == weights.dt_blob(synth.dt_state_dict(1, d=256, ff=1024), 4).size      # head width 32, ff = 4 d
+    assert floats(64, 64, 2) > 0 and floats(512, 512, 4, _lib.LAYOUT_CAN_FIRST | _lib.LAYOUT_NO_BAD | _lib.LAYOUT_SEP_AS_CAN) > 0
+    assert floats(64, 128, 8) == 0            # head width 8
+    assert floats(256, 384, 4) == 0           # ff not a multiple of d
+    assert floats(256, 9 * 256, 4) == 0       # ff > 8 d
+    assert floats(256, 512, 4, 8) == 0        # unknown layout bit
+    # a state_dict without the BAD token (input flavours without -BAD) packs into the same blob size
+    assert weights.dt_blob(synth.dt_state_dict(1, d=64, ff=128, flavour="MEM-SEP-CAN"), 4).size == floats(64, 128, 4, _lib.LAYOUT_NO_BAD)
     assert lib.busca_reid_blob_floats() == weights.reid_blob(synth.reid_state_dict(1)).size
     assert lib.busca_reid_workspace_bytes(8) > 8 * 5_000_000
 
