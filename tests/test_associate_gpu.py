@@ -147,6 +147,44 @@ def test_associate_exact_flavours_vs_reference(golden_dir, ci):
     assert np.array_equal(pm1, g["%s_probs_f64_sel1" % name])
 
 
+@pytest.mark.parametrize("flavour,sep_ref", [("MEM-CAN-SEP", False), ("MEM-SEP-CAN", True), ("MEM-CAN-SEP-BAD", True)])
+def test_associate_other_input_flavours_vs_oracle(golden_dir, flavour, sep_ref):
+    """associate_embeddings with a non-shipped token layout (P+1 probability columns without the BAD token): exact flavours against
+    the oracle chain (oracle ReID + oracle DT of that flavour - pinned to the reference by tests/golden/flavours_dt.npz - + oracle
+    host logic) on the first golden scene."""
+    from busca_amd.network import BUSCA
+    from oracle import associate as oa, dt as odt, reid as oreid
+    a = _args(precision="f32")
+    a.reid_precision = "f32"
+    a.input_flavour, a.encode_separator_as_reference = flavour, sep_ref
+    m = BUSCA(a).to(torch.device("cuda:0")).eval()
+    sd_dt, sd_reid = synth.dt_state_dict(23, d=64, ff=128, flavour=flavour), synth.reid_state_dict(17)
+    sd = dict(sd_dt)
+    sd.update({"reid_encoder.model." + k: v for k, v in sd_reid.items()})
+    m.load_state_dict(sd)
+    g = np.load(os.path.join(golden_dir, "assoc.npz"))
+    name, tracks, dets, kals, P = _case(0)
+    dists = g[name + "_dists"]
+    cfg = odt.DTConfig(d=64, ff=128, fake_f64=True, flavour=flavour, encode_sep_as_ref=sep_ref)
+
+    def step(mem_u8, can_u8, mem_ltrb, can_ltrb):
+        B, L = mem_u8.shape[:2]
+        P_ = can_u8.shape[1]
+        mf = oreid.reid_forward(sd_reid, oreid.crops_to_reid_input(mem_u8.reshape(B * L, 384, 128, 3))).view(B, L, -1)
+        cf = oreid.reid_forward(sd_reid, oreid.crops_to_reid_input(can_u8.reshape(B * P_, 384, 128, 3))).view(B, P_, -1)
+        return torch.softmax(odt.dt_forward(sd_dt, cfg, mf, cf, mem_ltrb, can_ltrb), -1).numpy()
+
+    for sel in (False, True):
+        want, wrel = oa.associate_embeddings(step, tracks, dets, dists, 11, P, True, sel, extra_kalman_candidates=kals)
+        got, rel = m.associate_embeddings(tracks, dets, dists, 11, P, True, sel, extra_kalman_candidates=kals, normalize_ims=True)
+        assert got.shape == want.shape and np.array_equal(rel, wrel)
+        assert m._last["probs"].shape[1] == P + (2 if "BAD" in flavour else 1)
+        if sel:
+            assert np.array_equal(got, want)
+        else:
+            assert np.abs(got - want).max() <= 2e-4, np.abs(got - want).max()
+
+
 def test_device_only_crops(model):
     """device_only_crops: get_image_crops skips the device->host copy; the crops associate through their pool slots
     (bit-identical), and ANY host read of such a crop (np.array, arithmetic, astype, pickle) returns the real pixels -
