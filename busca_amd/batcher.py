@@ -15,7 +15,7 @@ them queue back to back on the two ReID streams.
     probs_a, reliable_a = t1.result()        # bit-identical to model.associate_embeddings(tracks_a, ...)
 
 Bit-identical because the kernel FLAVOUR of a merged launch is pinned to what each step would get alone: the f16 fused kernel
-switches to two tracks per workgroup from 257 tracks on (agrees with the one-track flavour only to f16 rounding, ~3e-3 in the
+switches to two tracks per workgroup from 257 tracks on (where that needs fewer rounds of workgroups) (agrees with the one-track flavour only to f16 rounding, ~3e-3 in the
 logits), so the merged launch of steps that are each below that size is forced to the one-track flavour (`dt_ntrk` option of the
 context) and a step that is itself larger runs in its own launch; the row-tile geometry of the layer-wise path also follows the
 merged size, but its GEMMs sum every row in the same order whatever the tile (`tests/test_bench_gpu.py`, cfg5 split leg).

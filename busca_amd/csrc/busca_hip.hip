@@ -601,10 +601,13 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     const bool force_tiled = c->opt.dt_tiled != 0;          // testing: run the layer-wise path on any shape
     // the one-kernel path is built for the shipped geometry (four heads, ff = 2 d); other head counts / widths run layer-wise
     const bool fused_ok = !force_tiled && P + K.nspec <= 64 && c->dt.cfg.nhead == 4 && c->dt.cfg.ff == 2 * c->dt.cfg.d;
-    // f16: the fused kernel is bound by its weight stream, so from two rounds of workgroups on (B > 256 CUs) every workgroup
-    // takes TWO tracks and each streamed weight fragment feeds twice the tokens (BUSCA_DT_NTRK=1/2 forces either)
+    // f16, d = 256: from two rounds of workgroups on (B > 256 CUs) a workgroup can take TWO tracks (each streamed weight fragment feeds
+    // twice the tokens).  A two-track workgroup takes 1.88x as long as a one-track one (0.177 vs 0.094 ms per round, round 3), so the
+    // flavour with the shorter sum of rounds is taken: two tracks at 257-512 and 769-1024 tracks, one track at 513-768 (three rounds of
+    // 0.094 against two of 0.177) ... (BUSCA_DT_NTRK / option "dt_ntrk" = 1 / 2 forces either)
     const int ntrk_env = c->opt.dt_ntrk;
-    const bool two = ntrk_env == 2 || (ntrk_env == 0 && B > 256);
+    const long r1 = (B + 255) / 256, r2 = (B + 511) / 512;
+    const bool two = ntrk_env == 2 || (ntrk_env == 0 && B > 256 && r2 * 188 <= r1 * 100);
 #define DT_CASE2(M, DD, NCH) if (fused_ok && two && prec == 1 && MT == M && d == DD) return dt_launch<1, M, DD, 2 * DD, NCH, 2>(c, K, s)
     DT_CASE2(3, 256, 1); DT_CASE2(2, 256, 1);        // d = 512: the parked f32 residual does not fit the LDS plan
 #undef DT_CASE2
