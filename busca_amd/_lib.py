@@ -8,7 +8,8 @@ LIB_PATH = os.path.join(_HERE, "libbusca_hip.so")
 
 ACT_RELU, ACT_GELU = 0, 1
 LAYOUT_CAN_FIRST, LAYOUT_NO_BAD, LAYOUT_SEP_AS_CAN = 1, 2, 4      # busca_dt_cfg.layout bits
-PREC_F32, PREC_F16 = 0, 1
+PREC_F32, PREC_F16, PREC_F16X3 = 0, 1, 2
+ABI_MAJOR = 2                  # busca_version() // 1000 this binding was written for (include/busca_hip.h)
 PAIR_CENTER, PAIR_CENTER_WEIGHTED, PAIR_IOU, PAIR_IOU_COST = 0, 1, 2, 3
 
 
@@ -74,6 +75,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        v = lib.busca_version()
+        if v // 1000 != ABI_MAJOR:
+            raise ImportError("libbusca_hip.so has ABI version %d, this binding needs major %d - rebuild (python -m busca_amd.build --force)" % (v, ABI_MAJOR))
         _lib = lib
     return _lib
 

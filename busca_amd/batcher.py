@@ -71,11 +71,12 @@ class StepBatcher:
             can_feat = torch.cat([f[1] for f in feats], 0)
             mem_ltrb = torch.cat([torch.from_numpy(t._job["mem_ltrb"]) for t in ts], 0).to(dev)
             can_ltrb = torch.cat([torch.from_numpy(t._job["can_ltrb"]) for t in ts], 0).to(dev)
-            m._ctx.set_option("dt_ntrk", ntrk)
+            prev = m._ctx.get_option("dt_ntrk")                   # a pin (BUSCA_DT_NTRK / an earlier set_option) outranks the batcher's choice and survives it
+            m._ctx.set_option("dt_ntrk", prev if prev != 0 else ntrk)
             try:
                 out = m._dt.forward(mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=m.store_logits)
             finally:
-                m._ctx.set_option("dt_ntrk", 0)
+                m._ctx.set_option("dt_ntrk", prev)
             self.launches += 1
             lo = 0
             for t in ts:

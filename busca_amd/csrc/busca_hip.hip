@@ -28,6 +28,7 @@
 #include "reid_wdirect.hip.inc"
 #include "reid_pipe.hip.inc"
 #include "reid_f32.hip.inc"
+#include "reid_x3.hip.inc"
 #include "dt_tiled.hip.inc"
 #include "ecc_kernel.hip.inc"
 
@@ -110,7 +111,7 @@ static int ensure_lds(busca_ctx* c, const void* kern, size_t bytes) {
     return BUSCA_OK;
 }
 
-extern "C" int busca_version(void) { return 1001; }
+extern "C" int busca_version(void) { return 2000; }
 
 static std::string g_create_err;   // busca_last_error(NULL) reports why busca_ctx_create failed
 

@@ -7,6 +7,9 @@ import torch
 from . import weights
 
 
+PRECISIONS = {"f32": 0, "f16": 1, "x3": 2}          # BUSCA_PREC_F32 / _F16 / _F16X3 (include/busca_hip.h)
+
+
 def _ptr(t):
     return t.data_ptr() if t is not None else None
 
@@ -17,7 +20,11 @@ class ReIDEncoderHIP:
     PRETRAINED_SIZE = (384, 128)
 
     def __init__(self, ctx, state_dict, prefix="", precision="f16"):
-        """precision "f16": fp16 activations/weights (fast); "f32": exact float32 convs (reference-exact, ~6x slower)."""
+        """precision "f16": fp16 activations/weights (fastest, features ~6e-3 from the reference); "f32": exact float32 convs on the
+        f32 MFMA (reference-exact ~1e-5, ~6x slower); "x3": float32 activations with split-fp16 products, three fp16 MFMAs per block
+        (BUSCA_PREC_F16X3: the same ~1e-5 at a third of the fp16 matrix rate)."""
+        if precision not in PRECISIONS:
+            raise ValueError("ReID precision %r (one of %s)" % (precision, sorted(PRECISIONS)))
         self.ctx = ctx
         self.precision = precision
         self._blob = weights.reid_blob(state_dict, prefix)
@@ -27,7 +34,7 @@ class ReIDEncoderHIP:
 
     def _upload(self):
         ctx = self.ctx
-        ctx.check(ctx.lib.busca_reid_load_weights_ex(ctx.h, self._blob.ctypes.data, self._blob.size, {"f16": 1, "f32": 0}[self.precision]))
+        ctx.check(ctx.lib.busca_reid_load_weights_ex(ctx.h, self._blob.ctypes.data, self._blob.size, PRECISIONS[self.precision]))
         ctx.reid_owner = weakref.ref(self)
 
     def _ensure_loaded(self):

@@ -35,15 +35,19 @@ enum {
 };
 
 enum { BUSCA_ACT_RELU = 0, BUSCA_ACT_GELU = 1 };
-/* arithmetic of the dense contractions; LayerNorm / softmax / residual stream are always f32 */
-enum { BUSCA_PREC_F32 = 0, BUSCA_PREC_F16 = 1 };
+/* arithmetic of the dense contractions; LayerNorm / softmax / residual stream are always f32.
+ * BUSCA_PREC_F16X3 (ReID extractor, round 4): float32-EQUIVALENT products on the fp16 matrix cores - every f32 operand is split
+ * into fp16 hi + lo and a product block is three fp16 MFMAs into one f32 accumulator (error-corrected split GEMM; measured rms
+ * error 2.5e-8 of sum|a b| against float64, the f32 MFMA chain 2.8e-8); activations stay float32 in HBM, statistics float64. */
+enum { BUSCA_PREC_F32 = 0, BUSCA_PREC_F16 = 1, BUSCA_PREC_F16X3 = 2 };
 enum { BUSCA_PAIR_CENTER = 0, BUSCA_PAIR_CENTER_WEIGHTED = 1, BUSCA_PAIR_IOU = 2, BUSCA_PAIR_IOU_COST = 3 };
 
 /* ---- context ------------------------------------------------------------------------------ */
 int busca_ctx_create(int device, busca_ctx** out);
 void busca_ctx_destroy(busca_ctx* ctx);
 const char* busca_last_error(const busca_ctx* ctx);
-/* Library/ABI version: major*1000 + minor. */
+/* Library/ABI version: major*1000 + minor.  2000: busca_dt_cfg has the trailing `layout` field (36 bytes; a caller built against a
+ * 1xxx header passes 32) and BUSCA_PREC_F16X3 exists.  busca_amd/_lib.py refuses a library whose major differs from the one it was written for. */
 int busca_version(void);
 /* The compiler flags this library was built with (busca_amd/build.py passes them in; bench.py records the string). */
 const char* busca_build_info(void);
@@ -204,8 +208,10 @@ int busca_gather_crops(busca_ctx* ctx, const uint64_t* src, int32_t n, uint8_t* 
 /* Number of float32 values in the ReID weight blob (layout: see busca_amd/weights.py:reid_blob). */
 size_t busca_reid_blob_floats(void);
 int busca_reid_load_weights(busca_ctx* ctx, const float* blob, size_t blob_floats);      /* = _ex(..., BUSCA_PREC_F16) */
-/* precision BUSCA_PREC_F16: fp16 activations/weights, f32 accumulation and statistics (fast path).
- * precision BUSCA_PREC_F32: float32 activations/weights on exact-f32 MFMA - reference-exact (~1e-5), ~6x slower. */
+/* precision BUSCA_PREC_F16: fp16 activations/weights, f32 accumulation and statistics (fastest; features ~6e-3 from the reference).
+ * precision BUSCA_PREC_F32: float32 activations/weights on exact-f32 MFMA - reference-exact (~1e-5), ~6x slower than F16.
+ * precision BUSCA_PREC_F16X3: float32 activations, split-fp16 products (see the enum) - the same ~1e-5 against the reference at
+ *           a third of the fp16 MFMA rate instead of a sixteenth. */
 int busca_reid_load_weights_ex(busca_ctx* ctx, const float* blob, size_t blob_floats, int32_t precision);
 /* crops: dev u8 [n,384,128,3] BGR (what the trackers keep in images_mem).  feats: dev f32 [n,512],
  * L2-normalised.  ONE CALL == ONE BatchNorm batch (train-mode statistics, network.py:553-556). */

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_blob_sizes_and_version(lib):
     from busca_amd import _lib, synth, weights
-    assert lib.busca_version() >= 1001             # 1001: busca_dt_cfg.layout
+    assert lib.busca_version() // 1000 == 2         # 2000: busca_dt_cfg.layout is part of the ABI, BUSCA_PREC_F16X3
     for d in (64, 256, 512):
         cfg = _lib.DTCfg(d, 2 * d, 4, 4, 512, 0, 1, 0)
         blob = weights.dt_blob(synth.dt_state_dict(1, d=d, ff=2 * d), 4)

@@ -14,6 +14,9 @@ pytestmark = pytest.mark.gpu
 # deviation is the rounding of the fp16 design, not a defect.
 FEAT_ATOL = 1e-2
 COS_MIN = 0.9990
+# The two float32-class flavours: "f32" = float32 operands on v_mfma_f32_16x16x4_f32 (an fmaf chain), "x3" = float32 activations with
+# error-corrected split-fp16 products (three fp16 MFMAs per block, BUSCA_PREC_F16X3).  Both are held to the SAME bars.
+EXACT_FLAVOURS = ("f32", "x3")
 
 
 @pytest.fixture(scope="module")
@@ -72,8 +75,9 @@ def test_stem_pool_with_negative_batchnorm_scales(ctx, n):
     cos = (got * ref).sum(1)
     assert cos.min() >= COS_MIN, cos.min()
     assert np.abs(got - ref).max() <= FEAT_ATOL, np.abs(got - ref).max()
-    got32 = ReIDEncoderHIP(ctx, sd, precision="f32").forward(crops).cpu().numpy()
-    assert np.abs(got32 - ref).max() <= 5e-5, np.abs(got32 - ref).max()
+    for prec in EXACT_FLAVOURS:
+        got32 = ReIDEncoderHIP(ctx, sd, precision=prec).forward(crops).cpu().numpy()
+        assert np.abs(got32 - ref).max() <= 5e-5, (prec, np.abs(got32 - ref).max())
 
 
 def test_reid_batch_composition_matters(model):
@@ -88,16 +92,18 @@ def test_reid_batch_composition_matters(model):
     assert np.abs(part - full[:3]).max() > 1e-4
 
 
-def test_reid_f32_mode_matches_oracle(ctx):
-    """Exact-f32 flavour (f32 activations, v_mfma_f32_16x16x4_f32): float32-roundoff parity with the oracle, and it
-    bounds the fp16 flavour's deviation on the same batch."""
+@pytest.mark.parametrize("prec", EXACT_FLAVOURS)
+def test_reid_f32_mode_matches_oracle(ctx, prec):
+    """Float32-class flavours (f32 activations; v_mfma_f32_16x16x4_f32 or split-fp16 products): float32-roundoff parity with the
+    oracle, and they bound the fp16 flavour's deviation on the same batch."""
     from busca_amd.reid import ReIDEncoderHIP
     from oracle import reid as oreid
     sd = synth.reid_state_dict(3)
     crops = _crops(43, 3)
     ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
-    m32 = ReIDEncoderHIP(ctx, sd, precision="f32")
+    m32 = ReIDEncoderHIP(ctx, sd, precision=prec)
     got = m32.forward(crops).cpu().numpy()
+    print("%s vs oracle at 3 crops: %.2e" % (prec, np.abs(got - ref).max()))
     assert np.abs(got - ref).max() <= 5e-5, np.abs(got - ref).max()
     big = _crops(99, 24)
     f32 = m32.forward(big).cpu().numpy()
@@ -117,8 +123,10 @@ def test_reid_golden_reference_features(ctx, golden_dir):
     for n, seed in ((3, 43), (5, 45)):
         ref = g["feats_n%d_seed%d" % (n, seed)]
         crops = smooth_crops(seed, n)
-        got32 = ReIDEncoderHIP(ctx, sd, precision="f32").forward(crops).cpu().numpy()
-        assert np.abs(got32 - ref).max() <= 5e-5
+        for prec in EXACT_FLAVOURS:
+            got32 = ReIDEncoderHIP(ctx, sd, precision=prec).forward(crops).cpu().numpy()
+            print("%s vs the reference's features at %d crops: %.2e" % (prec, n, np.abs(got32 - ref).max()))
+            assert np.abs(got32 - ref).max() <= 5e-5, (prec, np.abs(got32 - ref).max())
         got16 = ReIDEncoderHIP(ctx, sd, precision="f16").forward(crops).cpu().numpy()
         assert ((got16 * ref).sum(1) >= COS_MIN).all()
 
@@ -143,11 +151,13 @@ def test_reid_default_large_batch_schedule_vs_reference(ctx, golden_dir, monkeyp
     cos = (got16 * ref).sum(1)
     assert cos.min() >= COS_MIN, cos.min()
     assert np.abs(got16 - ref).max() <= FEAT_ATOL, np.abs(got16 - ref).max()
-    got32 = ReIDEncoderHIP(ctx, sd, precision="f32").forward(crops).cpu().numpy()
     # float32 round-off through 53 conv + batch-statistics layers grows with the batch: the reference's own two CPU layouts
     # (channels_last vs contiguous input, see oracle/reid.py) already differ by 2.0e-5 at 96 crops; measured here
     # 5.2e-5 at 200 crops -> stated tolerance 1e-4 for these batch sizes (5e-5 stays the bar for the small batches above)
-    assert np.abs(got32 - ref).max() <= 1e-4, np.abs(got32 - ref).max()
+    for prec in EXACT_FLAVOURS:
+        got32 = ReIDEncoderHIP(ctx, sd, precision=prec).forward(crops).cpu().numpy()
+        print("%s vs the reference's features at %d crops: %.2e" % (prec, n, np.abs(got32 - ref).max()))
+        assert np.abs(got32 - ref).max() <= 1e-4, (prec, np.abs(got32 - ref).max())
 
 
 def test_reid_cfg4_sized_batches_vs_reference(ctx, golden_dir):
@@ -175,8 +185,10 @@ def test_reid_cfg4_sized_batches_vs_reference(ctx, golden_dir):
     # float32 batch statistics carry that much round-off.  The extractor accumulates statistics in float64, so its exact-f32
     # flavour is held to 2e-4 against the float64 result and to the reference's own error band (3e-3) against the reference.
     ref64 = np.load(os.path.join(golden_dir, "reid_cfg4_f64.npz"))["feats64_n%d_seed%d" % (n, seed)]
-    assert 1e-3 < np.abs(ref - ref64).max() < 3e-3
-    for prec, atol in (("f16", FEAT_ATOL), ("f32", 3e-3)):
+    # (the committed fixture is ONE run of the reference: regenerating it moves the features by ~1e-3, its float32 batch statistics
+    # depend on the run - so only the upper bound of the reference's distance from float64 is a property worth asserting)
+    assert np.abs(ref - ref64).max() < 3e-3
+    for prec, atol in (("f16", FEAT_ATOL), ("f32", 3e-3), ("x3", 3e-3)):
         m = ReIDEncoderHIP(ctx, sd, precision=prec)
         got = m.forward(crops).cpu().numpy()
         d, d64 = np.abs(got - ref).max(), np.abs(got - ref64).max()
@@ -445,7 +457,7 @@ def test_reid_fused_tail_conv1_path(ctx, monkeypatch):
     ReIDEncoderHIP(ctx, sd)
 
 
-@pytest.mark.parametrize("prec", ["f16", "f32"])
+@pytest.mark.parametrize("prec", ["f16", "f32", "x3"])
 def test_reid_weighted_statistics_equal_the_expanded_batch(ctx, prec):
     """busca_reid_forward_w: a BatchNorm batch in which crops repeat (the same detection among the candidates of several tracks,
     zero padding) given as distinct crops + multiplicities equals the forward over the expanded batch - up to floating-point
@@ -464,12 +476,12 @@ def test_reid_weighted_statistics_equal_the_expanded_batch(ctx, prec):
     full = m.forward(expanded).cpu().numpy()
     w = m.forward(uniq, weights=counts).cpu().numpy()[inverse]
     assert np.array_equal(m.forward(uniq, weights=counts).cpu().numpy()[inverse], w)            # deterministic
-    if prec == "f32":
+    if prec in EXACT_FLAVOURS:
         assert np.abs(w - full).max() <= 2e-5, np.abs(w - full).max()
     else:     # one flipped fp16 rounding early in the network moves the features by ~2e-3 (as between the other schedules)
         assert np.abs(w - full).max() <= 5e-3 and (w * full).sum(1).min() >= 0.9998
     ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(expanded)).numpy()
-    if prec == "f32":
+    if prec in EXACT_FLAVOURS:
         assert np.abs(w - ref).max() <= 5e-5
     else:
         assert (w * ref).sum(1).min() >= COS_MIN and np.abs(w - ref).max() <= FEAT_ATOL
