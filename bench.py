@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 from busca_amd import synth  # noqa: E402
 
 # MI355X_MICROARCH.md: f32-input MFMA peak (= f32 vector peak) 157.3 TFLOP/s; dense f16/bf16 MFMA 2500 TFLOP/s
-PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}
+PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "x3": 2500.0 / 3}      # x3: float32-equivalent products as three fp16 MFMAs (BUSCA_PREC_F16X3)
 REID_GFLOP_PER_CROP = 8.01          # SURVEY.md 2.1 (4.005 GMAC)
 
 
@@ -250,15 +250,17 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None, reid_precision="
     except Exception:
         traffic = None
     peak = PEAK_TFLOPS[reid_precision]
+    arith = {"f16": "fp16", "f32": "float32", "x3": "float32 split into fp16 hi + lo, three fp16 MFMAs per product block (float32-equivalent)"}[reid_precision]
+    extra = {"frac_of_f32_mfma_peak": tf / PEAK_TFLOPS["f32"], "peak_note": "peak = fp16 MFMA peak / 3 (three MFMAs per float32-equivalent product)"} if reid_precision == "x3" else {}
     return {"value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "crop_slots_per_step": slots, "crops_per_step": crops,
             "candidate_crops": "all distinct" if n_det is None else "%d slots drawn from %d detections (repeats computed once, weighted statistics)" % (B * P, n_det),
             "reid_algorithmic_tflop_per_step": crops * REID_GFLOP_PER_CROP / 1e3,
             "dtype": reid_precision, "dt_dtype": dt_model.precision,
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+            "roofline": dict({"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                          "traffic": traffic, "hbm_time_floor_ms": (traffic / 6.3e12 * 1e3) if traffic else None,
                          "note": "ReID convs (%s MFMA operands, f32 accumulate) + DT over the whole step; u8 crops already in HBM; traffic = PMC "
                                  "FETCH_SIZE x2 + WRITE_SIZE of a 512-crop pass (profiles/*reid_n512_pmc_traffic*.txt) scaled per crop, null "
-                                 "when no PMC run of this flavour is committed" % ("fp16" if reid_precision == "f16" else "float32")},
+                                 "when no PMC run of this flavour is committed" % arith}, **extra),
             "steps": n_steps}
 
 
@@ -282,6 +284,13 @@ def assoc_e2e(frames):
             gc.collect(); torch.cuda.empty_cache()
     except Exception as e:
         out["f32_lost32_dets118"] = {"error": repr(e)}
+    try:        # float32-equivalent ReID on split-fp16 MFMA + f32 Decision Transformer: the reference's tolerance at a fraction of the exact flavour's cost
+        for lost, objs in ((32, 150), (8, 60)):
+            r = e2e_sim.run(lost, objs, 5, 512, "f32", max(5, frames // 2), verbose=False, reid_precision="x3")
+            out["x3_lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in ("p50_assoc_latency_ms", "busca_frames_per_s", "precision", "reid_precision")}
+            gc.collect(); torch.cuda.empty_cache()
+    except Exception as e:
+        out["x3_lost32_dets118"] = {"error": repr(e)}
     r = e2e_sim.run(8, 60, 5, 512, "f16", frames, verbose=False, device_only_crops=True)     # opt-in: crops never copied back to the host
     out["lost8_dets52_device_only_crops"] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "busca_frames_per_s")}
     gc.collect(); torch.cuda.empty_cache()
@@ -290,7 +299,7 @@ def assoc_e2e(frames):
     except Exception as e:
         out["multi_sequence_4x_lost8"] = {"error": repr(e)}
     out["config"] = ("shipped model shape d=512 ff=1024 L=11 P=5, random weights, synthetic 1080p frames; default keys: f16 MFMA DT + fp16 ReID; "
-                     "f32_* keys: float32 DT + exact-f32 ReID (reference arithmetic)")
+                     "f32_* keys: float32 DT + exact-f32 ReID (reference arithmetic); x3_* keys: float32 DT + float32-equivalent ReID on split-fp16 MFMA")
     return out
 
 
@@ -559,6 +568,17 @@ def main():
                 ctx32.close()
             except Exception as e:
                 result["full_step_f32"] = {"error": repr(e)}
+            # ... and in float32-EQUIVALENT arithmetic on the fp16 matrix cores (BUSCA_PREC_F16X3 ReID: same parity bars as the exact
+            # flavour, tests/test_reid_gpu.py EXACT_FLAVOURS) + the f32 Decision Transformer
+            try:
+                ctx3 = _lib.Context(dev_index)
+                from busca_amd.dt import DecisionTransformerHIP
+                dt3 = DecisionTransformerHIP(ctx3, sd, activation="relu", fake_bbox_f64=True, precision="f32")
+                result["full_step_x3"] = full_step(ctx3, dt3, B, L, P, args.full_steps, dev, reid_precision="x3")
+                result["full_step_x3_tracker_like_candidates"] = full_step(ctx3, dt3, B, L, P, args.full_steps, dev, n_det=118, reid_precision="x3")
+                ctx3.close()
+            except Exception as e:
+                result["full_step_x3"] = {"error": repr(e)}
     if rank == 0:
         if args.cpu_seconds > 0:
             one = {k: v[:B] for k, v in big.items()}
