@@ -424,7 +424,7 @@ def main():
     backend = os.environ.get("BUSCA_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     if ndev < 1 or (backend == "nccl" and ndev < world):
-        print("bench.py: %d rank(s) but %d GPU(s) visible" % (world, ndev), file=sys.stderr)
+        print("bench.py: %d rank(s) but %d GPU(s) visible; refusing to fall back to fewer ranks" % (world, ndev), file=sys.stderr)
         sys.exit(2)
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)

@@ -28,10 +28,11 @@ CROP_BYTES = CROP_H * CROP_W * 3
 
 class Slot:
     """One live crop of the pool.  `ptr` is its device address (0 once spilled); `host` its host bytes (None until needed)."""
-    __slots__ = ("pool", "slab", "index", "ptr", "host", "__weakref__")
+    __slots__ = ("pool", "slab", "index", "ptr", "host", "host_src", "__weakref__")
 
     def __init__(self, pool, slab, index, ptr):
         self.pool, self.slab, self.index, self.ptr, self.host = pool, slab, index, ptr, None
+        self.host_src = None                # (frame host copy in flight, row): tracking.FrameHostCopy of get_image_crops' lazy mode
 
     def tensor(self):
         """cuda u8 [384,128,3] view of the slot, or None after a spill."""
@@ -39,6 +40,10 @@ class Slot:
 
     def host_bytes(self):
         """uint8 [384,128,3] host copy (device -> host on first use when the crop only lived in HBM)."""
+        if self.host is None and self.host_src is not None:
+            frame, k = self.host_src            # the frame's asynchronous device->host copy: wait for its event, then it is a plain view
+            self.host = frame.rows()[k]
+            self.host_src = None
         if self.host is None:
             if not self.ptr:
                 raise RuntimeError("crop slot lost both its device and its host copy")       # cannot happen: spill copies first

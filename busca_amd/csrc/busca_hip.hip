@@ -57,6 +57,7 @@ struct BuscaOptions {
     int dtl_rt = 0;           // BUSCA_DTL_RT: 2 / 4 = 64- / 128-row tiles of the layer-wise GEMMs (0 = automatic)
     int dtl_rt_mask = -1;     // BUSCA_DTL_RT_MASK: bit EPI = 64-row tiles for that GEMM kind (-1 = off)
     int dtl_glds = 0;         // BUSCA_DTL_GLDS: QKV / FFN1 through the direct-to-LDS GEMM
+    int dtl_ffn = 1;          // BUSCA_DTL_FFN: layer-wise path runs the feed-forward block as ONE kernel (0: FFN1 + FFN2 kernels, H through HBM)
     int dt_prof = 0;          // BUSCA_DT_PROF: phase stamps of the fused kernel (debug)
     int last_dt_grid = 0, last_dt_ntrk = 0;     // read-only: workgroups / tracks per workgroup of the last fused launch
     static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -64,6 +65,7 @@ struct BuscaOptions {
         dt_ntrk = env_int("BUSCA_DT_NTRK", 0); dt_tiled = getenv("BUSCA_DT_TILED") != nullptr ? 1 : 0;
         dtl_rt = env_int("BUSCA_DTL_RT", 0); dtl_rt_mask = env_int("BUSCA_DTL_RT_MASK", -1); dtl_glds = env_int("BUSCA_DTL_GLDS", 0);
         dt_prof = getenv("BUSCA_DT_PROF") != nullptr ? 1 : 0;
+        dtl_ffn = env_int("BUSCA_DTL_FFN", 1);
     }
 };
 
@@ -148,6 +150,7 @@ extern "C" int busca_set_option(busca_ctx* c, const char* name, int32_t value) {
     else if (n == "dtl_rt") o.dtl_rt = value;
     else if (n == "dtl_rt_mask") o.dtl_rt_mask = value;
     else if (n == "dtl_glds") o.dtl_glds = value;
+    else if (n == "dtl_ffn") o.dtl_ffn = value;
     else return fail(c, BUSCA_EINVAL, "busca_set_option: unknown option '%s'", name);
     return BUSCA_OK;
 }
@@ -160,6 +163,7 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
     else if (n == "dtl_rt") *value = o.dtl_rt;
     else if (n == "dtl_rt_mask") *value = o.dtl_rt_mask;
     else if (n == "dtl_glds") *value = o.dtl_glds;
+    else if (n == "dtl_ffn") *value = o.dtl_ffn;
     else if (n == "last_dt_grid") *value = o.last_dt_grid;
     else if (n == "last_dt_ntrk") *value = o.last_dt_ntrk;
     else return fail(c, BUSCA_EINVAL, "busca_get_option: unknown option '%s'", name);
@@ -560,6 +564,18 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
         { int rc = dtl_attention_hd<PREC>(c, s, MT, QKV, O, B, T, D, NH, att); if (rc) return rc; }
         a.A = O; a.lda = D; a.W = S.tw.w_out[l]; a.K = D; a.bias = W.b_out; a.gamma = W.g1; a.beta = W.be1;
         { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
+        if (D >= 256 && c->opt.dtl_ffn != 0) {
+            // feed-forward block in one kernel: H never reaches HBM (dtl_ffn_kernel)
+            DTLFfnArgs f{};
+            f.Xop = Xop; f.X = X; f.Xh = Xh; f.w1 = W.w1; f.w2 = W.w2; f.b1 = W.b1; f.b2 = W.b2; f.gamma = W.g2; f.beta = W.be2; f.M = (int)M; f.FF = FF; f.act = K.act;
+            constexpr int BMF = (PREC == 1 || D <= 256) ? 64 : 32;
+            constexpr size_t flds = (size_t)2 * BMF * (D * ES + 16) + (size_t)2 * 8 * BMF * 4;
+            auto kern = dtl_ffn_kernel<PREC, (D >= 256 ? D : 256)>;
+            { int rc = ensure_lds(c, (const void*)kern, flds); if (rc) return rc; }
+            TimedLaunch tl(c, s);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((M + BMF - 1) / BMF)), dim3(512), flds, s, f);
+            continue;
+        }
         a.A = Xop; a.lda = D; a.W = S.tw.w1[l]; a.K = D; a.bias = W.b1; a.out16 = H; a.ldo = FF;
         {
             int rc = BUSCA_OK;

@@ -92,11 +92,17 @@ class BUSCA:
                 raise NotImplementedError("only relu/gelu are built")
             self.effective_activation = args.activation
         self.precision = getattr(args, "precision", os.environ.get("BUSCA_AMD_PRECISION", "f32"))
-        # ReID flavour: "f16" (fp16 activations, fast) or "f32" (exact float32 convs, reference-exact, ~6x slower)
-        self.reid_precision = getattr(args, "reid_precision", os.environ.get("BUSCA_AMD_REID_PRECISION", "f16"))
+        # ReID flavour.  "x3" (default since round 4): float32 activations, float32-equivalent products as three fp16 MFMAs - features within
+        # 1e-5 of the reference's, association probabilities within 1e-3, identical decisions (tests/test_associate_gpu.py).  "f32": the same
+        # parity on the exact f32 MFMA, 2x slower.  "f16": fp16 activations, 2.2-2.8x faster than x3, but it moves probabilities by up to 0.03
+        # with random weights and flips 3.5 % of the `> 0.5` decisions of a sharp model (profiles/r04_decision_agreement.json): opt-in.
+        self.reid_precision = getattr(args, "reid_precision", os.environ.get("BUSCA_AMD_REID_PRECISION", "x3"))
         self.pinned_numpy = bool(getattr(args, "pinned_numpy_semantics", True))
         # True: get_image_crops(normalize=False) keeps the crops in the device pool only; host reads copy them back on demand
         self.device_only_crops = bool(getattr(args, "device_only_crops", False))
+        # host bytes of get_image_crops(normalize=False): "lazy" (default; copied to pinned memory on a side stream, waited for only by a
+        # host read), "eager" (a real ndarray, the call waits for the copy) - device_only_crops=True means "never"
+        self.crop_host_copy = getattr(args, "crop_host_copy", os.environ.get("BUSCA_AMD_CROP_HOST_COPY", "lazy"))
         self.store_logits = False           # set True to fill .logits / .mem_logits like the reference does
         # True: crops that occur several times in a BatchNorm batch (one detection among the candidates of many tracks, zero
         # padding) are computed once, with weighted batch statistics - same result up to summation order, less ReID work
@@ -542,7 +548,8 @@ class BUSCA:
         if output_size is not None and tuple(output_size) != (self.expected_image_size[1], self.expected_image_size[0]):
             raise NotImplementedError("only the ReID crop size 128x384 is built")
         self._sync()
-        return tracking.get_image_crops(image, bboxes, normalize=normalize, ctx=self._ctx, device_only=self.device_only_crops)
+        return tracking.get_image_crops(image, bboxes, normalize=normalize, ctx=self._ctx,
+                                        host_copy="never" if self.device_only_crops else self.crop_host_copy)
 
 
 class ReID_Encoder(_ReIDFacade):

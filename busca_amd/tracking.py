@@ -67,7 +67,8 @@ def multi_predict(stracks, ctx=None):
     nt = torch.from_numpy(np.asarray([st.state != TRACKED for st in stracks], dtype=np.uint8)).to(dev)
     ctx.check(ctx.lib.busca_kalman_multi_predict(ctx.h, mean.data_ptr(), cov.data_ptr(), nt.data_ptr(), len(stracks),
                                                  torch.cuda.current_stream(dev).cuda_stream))
-    mean, cov = mean.cpu().numpy(), cov.cpu().numpy()
+    both = torch.cat([mean, cov.view(len(stracks), 64)], 1).cpu().numpy()       # one device->host copy for both
+    mean, cov = np.ascontiguousarray(both[:, :8]), np.ascontiguousarray(both[:, 8:]).reshape(-1, 8, 8)
     for i, st in enumerate(stracks):
         st.mean = mean[i]
         st.covariance = cov[i]
@@ -87,7 +88,8 @@ def remove_duplicate_stracks(stracksa, stracksb, ctx=None, thresh=0.15):
     keep_b = torch.empty(len(stracksb), dtype=torch.uint8, device=dev)
     ctx.check(ctx.lib.busca_duplicate_masks(ctx.h, cost.data_ptr(), len(stracksa), len(stracksb), age_a.data_ptr(), age_b.data_ptr(),
                                             float(thresh), keep_a.data_ptr(), keep_b.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
-    ka, kb = keep_a.cpu().numpy(), keep_b.cpu().numpy()
+    kab = torch.cat([keep_a, keep_b]).cpu().numpy()                              # one device->host copy for both masks
+    ka, kb = kab[:len(stracksa)], kab[len(stracksa):]
     return [t for i, t in enumerate(stracksa) if ka[i]], [t for i, t in enumerate(stracksb) if kb[i]]
 
 
@@ -146,10 +148,28 @@ class DeviceBackedCrops(np.ndarray):
         return self.slot.tensor() if self.slot is not None else None
 
 
+class FrameHostCopy:
+    """The host bytes of one get_image_crops call, on their way: the crops were written into pool slots on the GPU; one
+    asynchronous device->host copy of all of them into PINNED memory runs on a side stream, and the first HOST read of any
+    of the crops waits for its event (usually long past).  A tracker that never looks at pixels never waits."""
+    __slots__ = ("host", "event", "_np")
+
+    def __init__(self, host, event):
+        self.host, self.event, self._np = host, event, None
+
+    def rows(self):
+        if self._np is None:
+            self.event.synchronize()
+            self._np = self.host.numpy()
+            self.event = None
+        return self._np
+
+
 class DeviceCrop(np.lib.mixins.NDArrayOperatorsMixin):
-    """One crop of `get_image_crops(..., device_only=True)`: lives in its pool slot only.  Any host read
-    (`np.array(crop)`, arithmetic, `.astype`, pickling) copies the real pixels back first - there are no placeholder
-    bytes that could leak into a BatchNorm batch."""
+    """One crop of `get_image_crops(..., normalize=False)` in its lazy (default) and device-only modes: lives in its pool slot;
+    any host read (`np.array(crop)`, arithmetic, `.astype`, pickling) returns the real pixels - from the frame's asynchronous
+    host copy (lazy mode) or by copying the slot back on demand (device-only mode).  There are no placeholder bytes that
+    could leak into a BatchNorm batch."""
     shape, dtype, ndim, size = (384, 128, 3), np.dtype(np.uint8), 3, 384 * 128 * 3
 
     def __init__(self, slot):
@@ -221,11 +241,25 @@ def box_extents(bboxes):
     return np.clip(r, -2.0 ** 30, 2.0 ** 30).astype(np.int32)
 
 
-def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False):
+_COPY_STREAMS = {}
+
+
+def _copy_stream(dev):
+    key = dev.index or 0
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(dev)
+    return _COPY_STREAMS[key]
+
+
+def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False, host_copy=None):
     """All crops of one frame in one launch: u8 BGR [N,384,128,3] (float32 normalised if `normalize`).
     With normalize=False every crop is written into a slot of the device crop pool and the returned crops remember
-    their slot.  `device_only`: skip the device->host copy of the crops (147 KB each, the bulk of this call); the
-    returned `DeviceCrops` copies pixels back only if something on the host actually reads them."""
+    their slot.  `host_copy` says what happens to the HOST bytes of those crops (147 KB each - the bulk of this call when it
+    is waited for; busca/network.py:492-507 returns host arrays):
+      "lazy"  (default) the copy of the whole batch into pinned memory is enqueued on a side stream and nobody waits: the
+              returned `DeviceCrops` hand out the pixels on the first host read (which waits for the copy's event);
+      "eager" wait for it: a real uint8 ndarray (`DeviceBackedCrops`) - for callers that need ndarray instances;
+      "never" (`device_only=True`) no copy at all; a host read copies that one crop back synchronously."""
     rects = box_extents(bboxes)
     if len(rects) == 0:
         return np.zeros([0, 128, 384, 3])            # the reference's (transposed) empty shape, network.py:503
@@ -233,13 +267,32 @@ def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False):
     if normalize:
         u8, _ = geometry.crop_gather(ctx, im, rects, want_u8=True)
         return normalize_crops(u8.cpu().numpy())
+    if host_copy is None:
+        host_copy = "never" if device_only else "lazy"
+    if host_copy not in ("lazy", "eager", "never"):
+        raise ValueError("host_copy must be 'lazy', 'eager' or 'never', not %r" % (host_copy,))
     pool = geometry.crop_pool(ctx)
     slots = pool.alloc(len(rects))
-    geometry.crop_gather(ctx, im, rects, want_u8=False, dst_ptrs=np.array([s.ptr for s in slots], dtype=np.uint64))
-    if device_only:
+    ptrs = np.array([s.ptr for s in slots], dtype=np.uint64)
+    geometry.crop_gather(ctx, im, rects, want_u8=False, dst_ptrs=ptrs)
+    if host_copy == "never":
         return DeviceCrops(slots)
-    host = geometry.gather_crops(ctx, np.array([s.ptr for s in slots], dtype=np.uint64)).cpu().numpy()
-    return DeviceBackedCrops(host, slots)
+    packed = geometry.gather_crops(ctx, ptrs)                 # the batch as one contiguous device buffer (the slots need not be adjacent)
+    if host_copy == "eager":
+        return DeviceBackedCrops(packed.cpu().numpy(), slots)
+    dev = packed.device
+    cur, side = torch.cuda.current_stream(dev), _copy_stream(dev)
+    host = torch.empty(packed.shape, dtype=torch.uint8, pin_memory=True)      # torch's caching host allocator: no hipHostMalloc per frame
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        host.copy_(packed, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    packed.record_stream(side)
+    frame = FrameHostCopy(host, ev)
+    for k, sl in enumerate(slots):
+        sl.host_src = (frame, k)
+    return DeviceCrops(slots)
 
 
 def get_bbox_crop(im, bbox_real_scale, output_size=(128, 384), normalize=True, ghost_normalize=True, ctx=None):

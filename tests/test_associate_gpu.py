@@ -98,17 +98,28 @@ def test_forward_accepts_reference_float_layout(model):
     assert model.logits.shape == (B, P + 2, 64) and model.mem_logits.shape == (B, 64) and len(model.attentions) == 4
 
 
-def test_device_resident_track_memory(model):
+@pytest.mark.parametrize("host_copy", ["lazy", "eager"])
+def test_device_resident_track_memory(model, host_copy):
     """Crops returned by get_image_crops keep a device twin; association then gathers them on the GPU
-    (no H2D) and gives bit-identical results to the host path."""
-    from busca_amd.tracking import DeviceBackedCrops
+    (no H2D) and gives bit-identical results to the host path.  "lazy" (the default): the host bytes arrive through an asynchronous
+    copy that only a host read waits for; "eager": a real ndarray, as in rounds 2-3."""
+    from busca_amd.tracking import DeviceBackedCrops, DeviceCrops
     import make_golden as mg
     model.pinned_numpy = True
     model._dirty = True
+    assert model.crop_host_copy == "lazy"                              # the default
     frame = synth.randint_u8(4, "frame", (540, 960, 3))
     boxes = np.array([[50 + 30 * i, 40 + 5 * i, 110 + 30 * i, 260 + 5 * i] for i in range(24)], np.float32)
-    crops = model.get_image_crops(frame, boxes, normalize=False)
-    assert isinstance(crops, DeviceBackedCrops) and crops[3].slot is not None and crops[3].dev is not None
+    model.crop_host_copy = host_copy
+    try:
+        crops = model.get_image_crops(frame, boxes, normalize=False)
+        again = model.get_image_crops(frame, boxes[:3], normalize=False)          # same frame object: its device copy is reused
+    finally:
+        model.crop_host_copy = "lazy"
+    assert np.array_equal(np.asarray(again[2]), np.asarray(crops[2]))
+    assert isinstance(crops, DeviceCrops if host_copy == "lazy" else DeviceBackedCrops) and crops[3].slot is not None and crops[3].dev is not None
+    if host_copy == "lazy":
+        assert crops[4].slot.host is None and crops[4].slot.host_src is not None     # nobody has read (or waited for) the host bytes yet
     assert np.array_equal(crops[3].dev.cpu().numpy(), np.asarray(crops[3]))
     assert type(np.array(crops[3])) is np.ndarray and getattr(np.array(crops[3]), "slot", None) is None
     hist = [mg.FakeTrack([[50, 40, 60, 220]] * 12, [crops[i] for i in range(12)]), mg.FakeTrack([[300, 80, 60, 220]] * 11, [crops[i] for i in range(12, 23)])]
