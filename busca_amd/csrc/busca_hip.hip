@@ -57,7 +57,8 @@ struct BuscaOptions {
     int dtl_rt = 0;           // BUSCA_DTL_RT: 2 / 4 = 64- / 128-row tiles of the layer-wise GEMMs (0 = automatic)
     int dtl_rt_mask = -1;     // BUSCA_DTL_RT_MASK: bit EPI = 64-row tiles for that GEMM kind (-1 = off)
     int dtl_glds = 0;         // BUSCA_DTL_GLDS: QKV / FFN1 through the direct-to-LDS GEMM
-    int dtl_ffn = 1;          // BUSCA_DTL_FFN: layer-wise path runs the feed-forward block as ONE kernel (0: FFN1 + FFN2 kernels, H through HBM)
+    int dtl_ffn = 2;          // BUSCA_DTL_FFN: 2 = the layer-wise path runs out-proj + norm1 + feed-forward + norm2 as ONE kernel, 1 = the feed-forward block only,
+                              // 0 = one kernel per GEMM (H and x1 through HBM)
     int dt_prof = 0;          // BUSCA_DT_PROF: phase stamps of the fused kernel (debug)
     int last_dt_grid = 0, last_dt_ntrk = 0;     // read-only: workgroups / tracks per workgroup of the last fused launch
     static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -65,7 +66,7 @@ struct BuscaOptions {
         dt_ntrk = env_int("BUSCA_DT_NTRK", 0); dt_tiled = getenv("BUSCA_DT_TILED") != nullptr ? 1 : 0;
         dtl_rt = env_int("BUSCA_DTL_RT", 0); dtl_rt_mask = env_int("BUSCA_DTL_RT_MASK", -1); dtl_glds = env_int("BUSCA_DTL_GLDS", 0);
         dt_prof = getenv("BUSCA_DT_PROF") != nullptr ? 1 : 0;
-        dtl_ffn = env_int("BUSCA_DTL_FFN", 1);
+        dtl_ffn = env_int("BUSCA_DTL_FFN", 2);
     }
 };
 
@@ -562,18 +563,29 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
         }
         float* att = K.att ? K.att + (size_t)l * B * NH * T * T : nullptr;
         { int rc = dtl_attention_hd<PREC>(c, s, MT, QKV, O, B, T, D, NH, att); if (rc) return rc; }
-        a.A = O; a.lda = D; a.W = S.tw.w_out[l]; a.K = D; a.bias = W.b_out; a.gamma = W.g1; a.beta = W.be1;
-        { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
-        if (D >= 256 && c->opt.dtl_ffn != 0) {
-            // feed-forward block in one kernel: H never reaches HBM (dtl_ffn_kernel)
+        const int ffn_mode = D >= 256 ? c->opt.dtl_ffn : 0;   // 2: out-proj + norm1 + feed-forward + norm2 in one kernel; 1: feed-forward block only; 0: layer-wise GEMMs
+        if (ffn_mode != 2) {
+            a.A = O; a.lda = D; a.W = S.tw.w_out[l]; a.K = D; a.bias = W.b_out; a.gamma = W.g1; a.beta = W.be1;
+            { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
+        }
+        if (ffn_mode != 0) {
+            // the row-local half of the layer in one kernel: x1 (mode 2) and H never reach HBM (dtl_ffn_kernel)
             DTLFfnArgs f{};
-            f.Xop = Xop; f.X = X; f.Xh = Xh; f.w1 = W.w1; f.w2 = W.w2; f.b1 = W.b1; f.b2 = W.b2; f.gamma = W.g2; f.beta = W.be2; f.M = (int)M; f.FF = FF; f.act = K.act;
-            constexpr int BMF = (PREC == 1 || D <= 256) ? 64 : 32;
-            constexpr size_t flds = (size_t)2 * BMF * (D * ES + 16) + (size_t)2 * 8 * BMF * 4;
-            auto kern = dtl_ffn_kernel<PREC, (D >= 256 ? D : 256)>;
-            { int rc = ensure_lds(c, (const void*)kern, flds); if (rc) return rc; }
+            f.Xop = Xop; f.Oop = O; f.X = X; f.Xh = Xh; f.w_out = W.w_out; f.w1 = W.w1; f.w2 = W.w2; f.b_out = W.b_out; f.g1 = W.g1; f.be1 = W.be1;
+            f.b1 = W.b1; f.b2 = W.b2; f.gamma = W.g2; f.beta = W.be2; f.M = (int)M; f.FF = FF; f.act = K.act;
+            constexpr int DK = D >= 256 ? D : 256;
+            constexpr int BMF = (PREC == 1 || DK <= 256) ? 64 : 32;
+            constexpr size_t flds = (size_t)2 * BMF * (DK * ES + 16) + (size_t)2 * 8 * BMF * 4;
             TimedLaunch tl(c, s);
-            hipLaunchKernelGGL(kern, dim3((unsigned)((M + BMF - 1) / BMF)), dim3(512), flds, s, f);
+            if (ffn_mode == 2) {
+                auto kern = dtl_ffn_kernel<PREC, DK, true>;
+                { int rc = ensure_lds(c, (const void*)kern, flds); if (rc) return rc; }
+                hipLaunchKernelGGL(kern, dim3((unsigned)((M + BMF - 1) / BMF)), dim3(512), flds, s, f);
+            } else {
+                auto kern = dtl_ffn_kernel<PREC, DK, false>;
+                { int rc = ensure_lds(c, (const void*)kern, flds); if (rc) return rc; }
+                hipLaunchKernelGGL(kern, dim3((unsigned)((M + BMF - 1) / BMF)), dim3(512), flds, s, f);
+            }
             continue;
         }
         a.A = Xop; a.lda = D; a.W = S.tw.w1[l]; a.K = D; a.bias = W.b1; a.out16 = H; a.ldo = FF;

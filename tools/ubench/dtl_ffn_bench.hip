@@ -32,18 +32,29 @@ static void pack(const std::vector<float>& W, int N, int K, int prec, std::vecto
             }
 }
 
-template <int PREC, int D>
+template <int PREC, int D, bool OUTPROJ = false, int PFV = 0>
 static void run(int M, int FF) {
     constexpr int ES = PREC == 0 ? 4 : 2;
-    std::vector<float> X((size_t)M * D), W1((size_t)FF * D), W2((size_t)D * FF), b1(FF), b2(D), g(D), be(D);
+    std::vector<float> X((size_t)M * D), W1((size_t)FF * D), W2((size_t)D * FF), b1(FF), b2(D), g(D), be(D), O((size_t)M * D), Wo((size_t)D * D), bo(D), g1(D), be1(D);
     for (auto& v : X) v = frand() * 1.5f;
+    for (auto& v : O) v = frand() * 1.5f;
+    for (auto& v : Wo) v = frand() / sqrtf((float)D) * 1.7f;
+    for (auto& v : bo) v = 0.1f * frand();
+    for (auto& v : g1) v = 1.0f + 0.2f * frand();
+    for (auto& v : be1) v = 0.1f * frand();
     for (auto& v : W1) v = frand() / sqrtf((float)D) * 1.7f;
     for (auto& v : W2) v = frand() / sqrtf((float)FF) * 1.7f;
     for (auto& v : b1) v = 0.1f * frand();
     for (auto& v : b2) v = 0.1f * frand();
     for (auto& v : g) v = 1.0f + 0.2f * frand();
     for (auto& v : be) v = 0.1f * frand();
-    std::vector<unsigned char> p1, p2; pack(W1, FF, D, PREC, p1); pack(W2, D, FF, PREC, p2);
+    std::vector<unsigned char> p1, p2, po; pack(W1, FF, D, PREC, p1); pack(W2, D, FF, PREC, p2); pack(Wo, D, D, PREC, po);
+    std::vector<unsigned char> Oop(O.size() * ES);
+    for (size_t i = 0; i < O.size(); ++i) { if (PREC == 0) ((float*)Oop.data())[i] = O[i]; else ((_Float16*)Oop.data())[i] = (_Float16)O[i]; }
+    void *dwo, *dO; float *dbo, *dg1, *dbe1;
+    CK(hipMalloc(&dwo, po.size())); CK(hipMalloc(&dO, Oop.size())); CK(hipMalloc(&dbo, D * 4)); CK(hipMalloc(&dg1, D * 4)); CK(hipMalloc(&dbe1, D * 4));
+    CK(hipMemcpy(dwo, po.data(), po.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(dO, Oop.data(), Oop.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dbo, bo.data(), D * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dg1, g1.data(), D * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dbe1, be1.data(), D * 4, hipMemcpyHostToDevice));
     std::vector<_Float16> Xh(X.size()); for (size_t i = 0; i < X.size(); ++i) Xh[i] = (_Float16)X[i];
     float *dX, *db1, *db2, *dg, *dbe; _Float16* dXh; void *dw1, *dw2;
     CK(hipMalloc(&dX, X.size() * 4)); CK(hipMalloc(&dXh, X.size() * 2)); CK(hipMalloc(&dw1, p1.size())); CK(hipMalloc(&dw2, p2.size()));
@@ -51,17 +62,18 @@ static void run(int M, int FF) {
     CK(hipMemcpy(dXh, Xh.data(), X.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw1, p1.data(), p1.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(dw2, p2.data(), p2.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(db1, b1.data(), FF * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db2, b2.data(), D * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dg, g.data(), D * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dbe, be.data(), D * 4, hipMemcpyHostToDevice));
     float* dH; CK(hipMalloc(&dH, (size_t)M * FF * 4)); CK(hipMemset(dH, 0, (size_t)M * FF * 4));
-    DTLFfnArgs f{}; f.dbg_h = dH;
+    DTLFfnArgs f{}; f.dbg_h = dH; f.Oop = dO; f.w_out = (const u32x4*)dwo; f.b_out = dbo; f.g1 = dg1; f.be1 = dbe1;
     f.Xop = PREC == 0 ? (const void*)dX : (const void*)dXh; f.X = dX; f.Xh = dXh; f.w1 = (const u32x4*)dw1; f.w2 = (const u32x4*)dw2; f.b1 = db1; f.b2 = db2; f.gamma = dg; f.beta = dbe; f.M = M; f.FF = FF; f.act = 0;
     constexpr int BMF = (PREC == 1 || D <= 256) ? 64 : 32;
     const size_t lds = (size_t)2 * BMF * (D * ES + 16) + (size_t)2 * 8 * BMF * 4;
-    CK(hipFuncSetAttribute((const void*)dtl_ffn_kernel<PREC, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)dtl_ffn_kernel<PREC, D, OUTPROJ, PFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms = 0;
+    fprintf(stderr, "launching <%d, %d, %d> M=%d\n", PREC, D, (int)OUTPROJ, M);
     for (int rep = 0; rep < 3; ++rep) {       // the kernel updates X in place: restore it every time
         CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dXh, Xh.data(), X.size() * 2, hipMemcpyHostToDevice));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((dtl_ffn_kernel<PREC, D>), dim3((M + BMF - 1) / BMF), dim3(512), lds, 0, f);
+        hipLaunchKernelGGL((dtl_ffn_kernel<PREC, D, OUTPROJ, PFV>), dim3((M + BMF - 1) / BMF), dim3(512), lds, 0, f);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
         CK(hipEventElapsedTime(&ms, e0, e1));
     }
@@ -72,11 +84,18 @@ static void run(int M, int FF) {
     std::vector<float> hH((size_t)M * FF); CK(hipMemcpy(hH.data(), dH, hH.size() * 4, hipMemcpyDeviceToHost));
     double maxerr = 0, maxh = 0; int rows = 0; double hyp[4] = {0, 0, 0, 0};
     for (int m = 0; m < M; m += (M > 64 ? M / 37 : 1)) {
-        std::vector<double> h(FF), o(D);
-        for (int j = 0; j < FF; ++j) { double s = 0; for (int k = 0; k < D; ++k) s += rnd(X[(size_t)m * D + k]) * rnd(W1[(size_t)j * D + k]); s += b1[j]; h[j] = rnd(s > 0 ? s : 0); }
+        std::vector<double> h(FF), o(D), x1(D);
+        for (int c = 0; c < D; ++c) x1[c] = X[(size_t)m * D + c];
+        if (OUTPROJ) {
+            double mn = 0;
+            for (int c = 0; c < D; ++c) { double s = 0; for (int k = 0; k < D; ++k) s += rnd(O[(size_t)m * D + k]) * rnd(Wo[(size_t)c * D + k]); x1[c] = s + bo[c] + X[(size_t)m * D + c]; mn += x1[c]; }
+            mn /= D; double vr = 0; for (int c = 0; c < D; ++c) vr += (x1[c] - mn) * (x1[c] - mn); vr /= D;
+            for (int c = 0; c < D; ++c) x1[c] = (double)(float)((x1[c] - mn) / sqrt(vr + 1e-5) * g1[c] + be1[c]);
+        }
+        for (int j = 0; j < FF; ++j) { double s = 0; for (int k = 0; k < D; ++k) s += rnd(x1[k]) * rnd(W1[(size_t)j * D + k]); s += b1[j]; h[j] = rnd(s > 0 ? s : 0); }
         for (int j = 0; j < FF; ++j) { const double e = fabs(h[j] - hH[(size_t)m * FF + j]); if (e > maxh) maxh = e; if (getenv("DBG") && e > 1e-2 && rows < 1) printf("  h mismatch row %d feature %d: got %f want %f\n", m, j, hH[(size_t)m * FF + j], h[j]); }
         double mean = 0;
-        for (int c = 0; c < D; ++c) { double s = 0; for (int j = 0; j < FF; ++j) s += h[j] * rnd(W2[(size_t)c * FF + j]); o[c] = s + b2[c] + X[(size_t)m * D + c]; mean += o[c]; }
+        for (int c = 0; c < D; ++c) { double s = 0; for (int j = 0; j < FF; ++j) s += h[j] * rnd(W2[(size_t)c * FF + j]); o[c] = s + b2[c] + x1[c]; mean += o[c]; }
         mean /= D; double var = 0; for (int c = 0; c < D; ++c) var += (o[c] - mean) * (o[c] - mean); var /= D;
         for (int c = 0; c < D; ++c) { const double want = (o[c] - mean) / sqrt(var + 1e-5) * g[c] + be[c]; maxerr = fmax(maxerr, fabs(want - out[(size_t)m * D + c])); }
         if (getenv("DBG") && rows < 2 && PREC == 0 && D == 256) {
@@ -86,7 +105,7 @@ static void run(int M, int FF) {
             printf("\n");
         }
         // hypotheses for a wrong result: 0 = no FFN term at all, 1 = only hidden block 0, 2 = only hidden block 1, 3 = hidden not activated
-        for (int hy = 0; hy < 4; ++hy) {
+        for (int hy = 0; hy < 4 && getenv("DBG") && rows < 2; ++hy) {
             std::vector<double> o2(D); double mn = 0;
             for (int c = 0; c < D; ++c) {
                 double sacc = 0;
@@ -95,10 +114,10 @@ static void run(int M, int FF) {
                     if (hy == 1 && j >= D) continue;
                     if (hy == 2 && j < D) continue;
                     double hv = h[j];
-                    if (hy == 3) { double t = 0; for (int k = 0; k < D; ++k) t += rnd(X[(size_t)m * D + k]) * rnd(W1[(size_t)j * D + k]); hv = rnd(t + b1[j]); }
+                    if (hy == 3) { double t = 0; for (int k = 0; k < D; ++k) t += rnd(x1[k]) * rnd(W1[(size_t)j * D + k]); hv = rnd(t + b1[j]); }
                     sacc += hv * rnd(W2[(size_t)c * FF + j]);
                 }
-                o2[c] = sacc + b2[c] + X[(size_t)m * D + c]; mn += o2[c];
+                o2[c] = sacc + b2[c] + x1[c]; mn += o2[c];
             }
             mn /= D; double vr = 0; for (int c = 0; c < D; ++c) vr += (o2[c] - mn) * (o2[c] - mn); vr /= D;
             for (int c = 0; c < D; ++c) hyp[hy] = fmax(hyp[hy], fabs((o2[c] - mn) / sqrt(vr + 1e-5) * g[c] + be[c] - out[(size_t)m * D + c]));
@@ -107,15 +126,22 @@ static void run(int M, int FF) {
         ++rows;
     }
     const double fl = 4.0 * M * D * (double)FF;
-    printf("dtl_ffn_kernel<%d, %d> M=%d ff=%d: %.1f us, %.1f TFLOP/s, max |err| %.2e (hidden layer %.2e) over %d sampled rows  %s\n", PREC, D, M, FF, ms * 1e3, fl / ms / 1e9, maxerr, maxh, rows,
+    printf("dtl_ffn_kernel<%d, %d, %d, pf %d> M=%d ff=%d: %.1f us, %.1f TFLOP/s, max |err| %.2e (hidden layer %.2e) over %d sampled rows  %s\n", PREC, D, (int)OUTPROJ, PFV, M, FF, ms * 1e3, (fl + (OUTPROJ ? 2.0 * M * D * (double)D : 0.0)) / ms / 1e9, maxerr, maxh, rows,
            maxerr < (PREC == 0 ? 2e-4 : 2e-2) ? "OK" : "FAIL");
+    fflush(stdout);
     if (maxerr >= (PREC == 0 ? 2e-4 : 2e-2)) printf("    distance to: no FFN term %.2e | hidden block 0 only %.2e | hidden block 1 only %.2e | no activation %.2e\n", hyp[0], hyp[1], hyp[2], hyp[3]);
-    hipFree(dX); hipFree(dXh); hipFree(dw1); hipFree(dw2); hipFree(db1); hipFree(db2); hipFree(dg); hipFree(dbe);
+    hipFree(dwo); hipFree(dO); hipFree(dbo); hipFree(dg1); hipFree(dbe1); hipFree(dH); hipFree(dX); hipFree(dXh); hipFree(dw1); hipFree(dw2); hipFree(db1); hipFree(db2); hipFree(dg); hipFree(dbe);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && atoi(argv[1]) == 1) { run<1, 512, true>(64, 1024); run<1, 512, true>(800, 1024); return 0; }
+    if (argc > 1 && atoi(argv[1]) == 2) { run<1, 512, false>(64, 1024); run<1, 512, false>(800, 1024); return 0; }
+    if (argc > 1 && atoi(argv[1]) == 3) { run<0, 512, true>(64, 1024); run<0, 512, true>(800, 1024); return 0; }
     run<0, 128>(150, 256); run<1, 128>(150, 256); run<0, 384>(150, 768); run<1, 384>(150, 768);
-    run<1, 256>(1504, 512); run<0, 256>(1504, 512); run<0, 256>(64, 256); run<1, 512>(800, 1024); run<0, 512>(800, 1024);
-    if (getenv("BIG")) { run<1, 512>(73216, 1024); run<0, 512>(20224, 1024); run<1, 256>(73216, 512); }
+    run<1, 256>(1504, 512); run<0, 256>(1504, 512); run<0, 256>(64, 256);
+    run<1, 256, true>(1504, 512); run<0, 256, true>(1504, 512); run<1, 512, true>(800, 1024); run<0, 512, true>(800, 1024); run<1, 384, true>(150, 768); run<1, 512>(800, 1024); run<0, 512>(800, 1024);
+    run<1, 512, false>(800, 1024); run<1, 512, true>(800, 1024); run<0, 512, true>(800, 1024);
+    if (getenv("BIG")) { run<1, 512, false, 2>(73216, 1024); run<1, 512, false, 4>(73216, 1024); run<1, 512, true, 2>(73216, 1024); run<1, 512, true, 4>(73216, 1024);
+                         run<0, 512>(20224, 1024); run<0, 512, true>(20224, 1024); run<1, 256, true>(73216, 512); }
     return 0;
 }
