@@ -59,6 +59,7 @@ struct BuscaOptions {
     int dtl_glds = 0;         // BUSCA_DTL_GLDS: QKV / FFN1 through the direct-to-LDS GEMM
     int dtl_ffn = 2;          // BUSCA_DTL_FFN: 2 = the layer-wise path runs out-proj + norm1 + feed-forward + norm2 as ONE kernel, 1 = the feed-forward block only,
                               // 0 = one kernel per GEMM (H and x1 through HBM)
+    int dtl_attn = 1;         // BUSCA_DTL_ATTN: 1 = QKV projection + attention of a (track, head) in one kernel where it is built (0: QKV GEMM + attention kernel)
     int dt_prof = 0;          // BUSCA_DT_PROF: phase stamps of the fused kernel (debug)
     int last_dt_grid = 0, last_dt_ntrk = 0;     // read-only: workgroups / tracks per workgroup of the last fused launch
     static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -66,7 +67,7 @@ struct BuscaOptions {
         dt_ntrk = env_int("BUSCA_DT_NTRK", 0); dt_tiled = getenv("BUSCA_DT_TILED") != nullptr ? 1 : 0;
         dtl_rt = env_int("BUSCA_DTL_RT", 0); dtl_rt_mask = env_int("BUSCA_DTL_RT_MASK", -1); dtl_glds = env_int("BUSCA_DTL_GLDS", 0);
         dt_prof = getenv("BUSCA_DT_PROF") != nullptr ? 1 : 0;
-        dtl_ffn = env_int("BUSCA_DTL_FFN", 2);
+        dtl_ffn = env_int("BUSCA_DTL_FFN", 2); dtl_attn = env_int("BUSCA_DTL_ATTN", 1);
     }
 };
 
@@ -152,6 +153,7 @@ extern "C" int busca_set_option(busca_ctx* c, const char* name, int32_t value) {
     else if (n == "dtl_rt_mask") o.dtl_rt_mask = value;
     else if (n == "dtl_glds") o.dtl_glds = value;
     else if (n == "dtl_ffn") o.dtl_ffn = value;
+    else if (n == "dtl_attn") o.dtl_attn = value;
     else return fail(c, BUSCA_EINVAL, "busca_set_option: unknown option '%s'", name);
     return BUSCA_OK;
 }
@@ -165,6 +167,7 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
     else if (n == "dtl_rt_mask") *value = o.dtl_rt_mask;
     else if (n == "dtl_glds") *value = o.dtl_glds;
     else if (n == "dtl_ffn") *value = o.dtl_ffn;
+    else if (n == "dtl_attn") *value = o.dtl_attn;
     else if (n == "last_dt_grid") *value = o.last_dt_grid;
     else if (n == "last_dt_ntrk") *value = o.last_dt_ntrk;
     else return fail(c, BUSCA_EINVAL, "busca_get_option: unknown option '%s'", name);
@@ -509,6 +512,32 @@ static int dtl_attention_hd(busca_ctx* c, hipStream_t s, int MT, const void* qkv
     return fail(c, BUSCA_EINVAL, "tiled attention: head width %d not built (16, 32, 64, 128)", D / NH);
 }
 
+// QKV projection + attention of a (track, head) in one kernel (dtl_qkv_attn_kernel): built for the shipped head geometry (four heads: d = 512 /
+// 128-wide, d = 256 / 64-wide) and the token counts the one-kernel path cannot hold.  Returns false when this shape is not built.
+template <int PREC, int D, int HD, int MT>
+static int dtl_qkv_attn_launch(busca_ctx* c, hipStream_t s, const DTLQkvAttnArgs& a, int B) {
+    constexpr int ES = Prec<PREC>::ES, CH = Prec<PREC>::CHUNK, TP = 16 * MT, TPK = CH * Prec<PREC>::nchunks(MT);
+    constexpr size_t ga = (size_t)TP * ((D / 2) * ES + 16), at = (size_t)2 * TP * (HD * ES + 16) + (size_t)HD * (TPK * ES + 16);
+    constexpr size_t lds = ga > at ? ga : at;
+    static_assert(lds <= 160 * 1024, "fused QKV + attention: LDS plan");
+    auto kern = dtl_qkv_attn_kernel<PREC, D, HD, MT>;
+    { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
+    TimedLaunch tl(c, s);
+    hipLaunchKernelGGL(kern, dim3(B, a.NH), dim3(4 * HD), lds, s, a);
+    return BUSCA_OK;
+}
+template <int PREC, int D>
+static bool dtl_qkv_attn(busca_ctx* c, hipStream_t s, const DTLQkvAttnArgs& a, int B, int MT, int* rc) {
+    constexpr int HD = D / 4;
+    *rc = BUSCA_OK;
+    if (D < 256 || a.NH != 4) return false;
+#define QA(M_) case M_: *rc = dtl_qkv_attn_launch<PREC, (D >= 256 ? D : 256), (D >= 256 ? HD : 64), M_>(c, s, a, B); return true
+    if constexpr (PREC == 1) { switch (MT) { QA(5); QA(6); QA(7); QA(8); QA(9); } }
+    else { switch (MT) { QA(3); QA(4); QA(5); } }
+#undef QA
+    return false;
+}
+
 // Workspace of the layer-wise path for M rows (bytes).  Grown outside the forward by busca_dt_reserve; a forward that finds
 // it too small grows it itself (one stream synchronisation + hipMalloc, first call of a larger shape only).
 static size_t dtl_ws_bytes(size_t M, int D, int FF, size_t es) {
@@ -555,14 +584,24 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     { int rc = dtl_gemm<PREC, D, DTL_EPI_EMBED>(c, s, a, 1); if (rc) return rc; }
     for (int l = 0; l < K.nlayers; ++l) {
         const DTLayerW& W = K.layer[l];
-        a.A = Xop; a.lda = D; a.W = S.tw.w_in[l]; a.K = D; a.bias = W.b_in; a.out16 = QKV; a.ldo = 3 * D;
-        {
+        float* att = K.att ? K.att + (size_t)l * B * NH * T * T : nullptr;
+        bool fused_attn = false;
+        if (c->opt.dtl_attn != 0) {
+            DTLQkvAttnArgs q{};
+            q.Xop = Xop; q.w_in = W.w_in; q.b_in = W.b_in; q.O = O; q.att = att; q.T = T; q.NH = NH; q.qscale = a.qscale;
             int rc = BUSCA_OK;
-            if (!(PREC == 1 && dtl_gemm_glds<GEMM_EPI_BIAS_QSCALE>(c, s, a, 3 * D, D, &rc))) rc = dtl_gemm<PREC, D, DTL_EPI_QKV>(c, s, a, 3);
+            fused_attn = dtl_qkv_attn<PREC, D>(c, s, q, B, MT, &rc);
             if (rc) return rc;
         }
-        float* att = K.att ? K.att + (size_t)l * B * NH * T * T : nullptr;
-        { int rc = dtl_attention_hd<PREC>(c, s, MT, QKV, O, B, T, D, NH, att); if (rc) return rc; }
+        if (!fused_attn) {
+            a.A = Xop; a.lda = D; a.W = S.tw.w_in[l]; a.K = D; a.bias = W.b_in; a.out16 = QKV; a.ldo = 3 * D;
+            {
+                int rc = BUSCA_OK;
+                if (!(PREC == 1 && dtl_gemm_glds<GEMM_EPI_BIAS_QSCALE>(c, s, a, 3 * D, D, &rc))) rc = dtl_gemm<PREC, D, DTL_EPI_QKV>(c, s, a, 3);
+                if (rc) return rc;
+            }
+            { int rc = dtl_attention_hd<PREC>(c, s, MT, QKV, O, B, T, D, NH, att); if (rc) return rc; }
+        }
         const int ffn_mode = D >= 256 ? c->opt.dtl_ffn : 0;   // 2: out-proj + norm1 + feed-forward + norm2 in one kernel; 1: feed-forward block only; 0: layer-wise GEMMs
         if (ffn_mode != 2) {
             a.A = O; a.lda = D; a.W = S.tw.w_out[l]; a.K = D; a.bias = W.b_out; a.gamma = W.g1; a.beta = W.be1;
