@@ -143,10 +143,36 @@ extern "C" int busca_ctx_create(int device, busca_ctx** out) {
 #endif
 extern "C" const char* busca_build_info(void) { return "libbusca_hip gfx950 flags: " BUSCA_BUILD_FLAGS; }
 
+// ReID schedule knobs by name ("reid_gram", "reid_halo", ...): the same fields the BUSCA_REID_* environment variables set when weights are
+// loaded; through busca_set_option they change between two forwards of a loaded extractor (A/B runs, the tests that compare schedules).
+static int* reid_option_field(ReidState& R, const std::string& n) {
+    struct { const char* name; int* p; } tab[] = {
+        {"reid_gram", &R.gram_mode}, {"reid_splitk_blocks", &R.splitk_blocks}, {"reid_halo_min", &R.halo_min_blocks}, {"reid_halo_half", &R.halo_half_blocks},
+        {"reid_halo_wpx", &R.halo_wpx}, {"reid_halo_wpx_min", &R.halo_wpx_min}, {"reid_gram_min", &R.gram_min_pixels}, {"reid_direct_rows", &R.direct_rows},
+        {"reid_fuse_ds_layers", &R.fuse_ds_layers}, {"reid_fuse_c1_layers", &R.fuse_c1_layers}, {"reid_kwave_blocks", &R.kwave_blocks},
+        {"reid_kwave_halo", &R.kwave_halo_blocks}, {"reid_kwave_nw", &R.kwave_nw}, {"reid_kwave_pt", &R.kwave_pt}, {"reid_glds_min", &R.glds_min_tiles},
+        {"reid_glds_bm", &R.glds_bm}, {"reid_wd_min", &R.wd_min_tiles}, {"reid_pipe_min", &R.pipe_min_tiles}, {"reid_pipe_half", &R.pipe_half_blocks},
+        {"reid_x3_merge_layers", &R.x3_merge_layers}, {"reid_x3_half", &R.x3_half_blocks}};
+    for (auto& e : tab) if (n == e.name) return e.p;
+    return nullptr;
+}
+static bool* reid_option_flag(ReidState& R, const std::string& n) {
+    struct { const char* name; bool* p; } tab[] = {{"reid_halo", &R.halo}, {"reid_fuse_c1", &R.fuse_c1}, {"reid_fuse_c1_small", &R.fuse_c1_small},
+                                                   {"reid_stats2", &R.two_launch_stats}, {"reid_pipe_all", &R.pipe_all}, {"reid_wd_all", &R.wd_all}};
+    for (auto& e : tab) if (n == e.name) return e.p;
+    return nullptr;
+}
+
 extern "C" int busca_set_option(busca_ctx* c, const char* name, int32_t value) {
     if (!c || !name) return BUSCA_EINVAL;
     BuscaOptions& o = c->opt;
     const std::string n(name);
+    if (n.rfind("reid_", 0) == 0) {
+        if (!c->reid.loaded) return fail(c, BUSCA_ENOWEIGHTS, "busca_set_option('%s'): ReID schedule options belong to a loaded extractor (load weights first)", name);
+        if (int* p = reid_option_field(c->reid, n)) { *p = value; return BUSCA_OK; }
+        if (bool* p = reid_option_flag(c->reid, n)) { *p = value != 0; return BUSCA_OK; }
+        return fail(c, BUSCA_EINVAL, "busca_set_option: unknown option '%s'", name);
+    }
     if (n == "dt_ntrk") o.dt_ntrk = value;
     else if (n == "dt_tiled") o.dt_tiled = value;
     else if (n == "dtl_rt") o.dtl_rt = value;
@@ -161,6 +187,11 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
     if (!c || !name || !value) return BUSCA_EINVAL;
     const BuscaOptions& o = c->opt;
     const std::string n(name);
+    if (n.rfind("reid_", 0) == 0) {
+        if (int* p = reid_option_field(c->reid, n)) { *value = *p; return BUSCA_OK; }
+        if (bool* p = reid_option_flag(c->reid, n)) { *value = *p ? 1 : 0; return BUSCA_OK; }
+        return fail(c, BUSCA_EINVAL, "busca_get_option: unknown option '%s'", name);
+    }
     if (n == "dt_ntrk") *value = o.dt_ntrk;
     else if (n == "dt_tiled") *value = o.dt_tiled;
     else if (n == "dtl_rt") *value = o.dtl_rt;

@@ -356,8 +356,8 @@ def evaluate(results_dir, sequences):
     """Score result files against the sequences' ground truth.  Uses motmetrics when importable (the evaluator ByteTrack calls,
     adapters/ByteTrack/tools/track.py:236-287: `mm.utils.compare_to_groundtruth` walks the UNION of ground-truth and result
     frames, so tracker rows in frames without ground truth count as false positives - same here); otherwise the built-in
-    CLEAR-MOT / IDF1 scorer.  HOTA is always the built-in restatement of TrackEval's (GHOST eval_track_eval.py:70 calls the real
-    one; it is not wired in - `trackeval_available()` only tells a caller whether it could run it on the written files itself).
+    CLEAR-MOT / IDF1 scorer.  HOTA here is the built-in restatement of TrackEval's; `run_trackeval` (below, `tools/run_mot.py
+    --trackeval`) runs TrackEval ITSELF on the written files when it is importable, as GHOST's eval_track_eval.py:70 does.
     Returns {sequence: metrics dict}."""
     out = {}
     for seq in sequences:
@@ -380,9 +380,61 @@ def evaluate(results_dir, sequences):
     return out
 
 
-def trackeval_available():
+def _import_trackeval():
     try:
-        import trackeval  # noqa: F401
-        return True
+        import trackeval
+        return trackeval
     except ImportError:
-        return False
+        try:                                                  # GHOST vendors it under this name (adapters/GHOST/src/eval_track_eval.py:1)
+            from TrackEvalForGHOST import trackeval
+            return trackeval
+        except ImportError:
+            return None
+
+
+def trackeval_available():
+    return _import_trackeval() is not None
+
+
+def run_trackeval(results_dir, sequences, gt_root, tracker_name="busca_amd", work_dir=None, metrics=("HOTA", "CLEAR", "Identity")):
+    """TrackEval's own MOTChallenge2DBox evaluation of the written result files - the runner GHOST calls
+    (adapters/GHOST/src/eval_track_eval.py:70-125: Evaluator + datasets.MotChallenge2DBox + metrics HOTA / CLEAR / Identity,
+    threshold 0.5, SKIP_SPLIT_FOL, explicit SEQ_INFO).  `gt_root` holds <sequence>/gt/gt.txt (+ seqinfo.ini) as MOT17/train does.
+    The result files are linked into the layout TrackEval reads (<work>/<tracker_name>/<sequence>.txt).  Returns
+    {sequence: {"HOTA", "DetA", "AssA", "MOTA", "IDF1", "IDSW", ...}} plus "COMBINED_SEQ" - TrackEval's numbers, not this module's
+    restatements; None when TrackEval is not importable (it is not in the build image)."""
+    te = _import_trackeval()
+    if te is None:
+        return None
+    import shutil
+    import tempfile
+    work = work_dir or tempfile.mkdtemp(prefix="busca_trackeval_")
+    tdir = os.path.join(work, tracker_name)
+    os.makedirs(tdir, exist_ok=True)
+    for seq in sequences:
+        src = os.path.join(results_dir, seq.name + ".txt")
+        if os.path.exists(src):
+            shutil.copyfile(src, os.path.join(tdir, seq.name + ".txt"))
+    eval_cfg = te.Evaluator.get_default_eval_config()
+    data_cfg = te.datasets.MotChallenge2DBox.get_default_dataset_config()
+    eval_cfg.update({"PRINT_CONFIG": False, "PRINT_RESULTS": False, "DISPLAY_LESS_PROGRESS": True, "TIME_PROGRESS": False, "USE_PARALLEL": False,
+                     "OUTPUT_SUMMARY": False, "OUTPUT_DETAILED": False, "PLOT_CURVES": False})
+    data_cfg.update({"GT_FOLDER": gt_root, "TRACKERS_FOLDER": work, "TRACKERS_TO_EVAL": [tracker_name], "OUTPUT_FOLDER": os.path.join(work, "track_eval_output"),
+                     "PRINT_CONFIG": False, "SKIP_SPLIT_FOL": True, "TRACKER_SUB_FOLDER": "", "SEQ_INFO": {seq.name: len(seq) for seq in sequences}})
+    mcfg = {"METRICS": list(metrics), "THRESHOLD": 0.5, "PRINT_CONFIG": False}
+    mlist = [m(mcfg) for m in (te.metrics.HOTA, te.metrics.CLEAR, te.metrics.Identity) if m.get_name() in mcfg["METRICS"]]
+    res, _msg = te.Evaluator(eval_cfg).evaluate([te.datasets.MotChallenge2DBox(data_cfg)], mlist)
+    per = res["MotChallenge2DBox"][tracker_name]
+    out = {}
+    for name, r in per.items():
+        r = r.get("pedestrian", r)
+        row = {}
+        if "HOTA" in r:
+            row.update({k: float(np.mean(r["HOTA"][k])) for k in ("HOTA", "DetA", "AssA")})
+        if "CLEAR" in r:
+            row.update({"MOTA": float(r["CLEAR"]["MOTA"]), "IDSW": int(r["CLEAR"]["IDSW"]), "FP": int(r["CLEAR"]["CLR_FP"]), "FN": int(r["CLEAR"]["CLR_FN"])})
+        if "Identity" in r:
+            row["IDF1"] = float(r["Identity"]["IDF1"])
+        row["scorer"] = "TrackEval"
+        out[name] = row
+    return out

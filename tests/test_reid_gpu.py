@@ -502,3 +502,43 @@ def test_reid_weighted_statistics_large_duplication(ctx):
     full = m.forward(uniq[inverse]).cpu().numpy()
     w = m.forward(uniq, weights=counts).cpu().numpy()[inverse]
     assert np.abs(w - full).max() <= 5e-3 and (w * full).sum(1).min() >= 0.9998
+
+
+def test_reid_schedule_options_change_between_forwards(ctx):
+    """The ReID schedule knobs are per-context options of a loaded extractor (busca_set_option "reid_*"), not only BUSCA_REID_* variables
+    latched at load time: flipping the halo-resident 3x3 kernel / the fused tails off between two forwards of the SAME handle gives the
+    plain-schedule result (within the schedules' summation-order band), flipping them back restores the first result bit for bit."""
+    from busca_amd import _lib
+    from busca_amd.reid import ReIDEncoderHIP
+    sd = synth.reid_state_dict(3)
+    m = ReIDEncoderHIP(ctx, sd, precision="f16")
+    crops = _crops(611, 24)
+    a = m.forward(crops).cpu().numpy()
+    assert ctx.get_option("reid_halo") == 1 and ctx.get_option("reid_fuse_c1") == 1
+    ctx.set_option("reid_halo", 0); ctx.set_option("reid_fuse_c1", 0); ctx.set_option("reid_gram", 0)
+    try:
+        b = m.forward(crops).cpu().numpy()
+    finally:
+        ctx.set_option("reid_halo", 1); ctx.set_option("reid_fuse_c1", 1); ctx.set_option("reid_gram", -1)
+    c = m.forward(crops).cpu().numpy()
+    assert np.array_equal(a, c)
+    assert np.abs(a - b).max() <= 5e-3 and (a * b).sum(1).min() >= 0.9998
+    with pytest.raises(_lib.BuscaError):
+        ctx.set_option("reid_no_such_knob", 1)
+
+
+def test_reid_weighted_batch_with_many_distinct_crops(ctx):
+    """A weighted BatchNorm batch with more distinct crops than the Gram-statistics scratch holds chunk partials for (a weighted pass cuts its
+    chunks at crop boundaries: ~one chunk per crop; from ~615 distinct crops the 256-channel downsample input of layer 2 no longer fits): the
+    forward must take the direct-statistics schedule instead of failing with BUSCA_EINVAL (round-3 advisor finding), and agree with the
+    expanded batch."""
+    from busca_amd.reid import ReIDEncoderHIP
+    sd = synth.reid_state_dict(3)
+    uniq = _crops(7001, 700)
+    counts = np.where(np.arange(700) % 2 == 0, 2, 1)
+    inverse = np.repeat(np.arange(700), counts)
+    m = ReIDEncoderHIP(ctx, sd, precision="f16")
+    w = m.forward(uniq, weights=counts).cpu().numpy()
+    full = m.forward(torch.from_numpy(uniq).cuda()[torch.from_numpy(inverse).cuda()]).cpu().numpy()
+    first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    assert np.abs(w - full[first]).max() <= 5e-3 and (w * full[first]).sum(1).min() >= 0.9998

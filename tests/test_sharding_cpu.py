@@ -101,9 +101,10 @@ def test_two_rank_bookkeeping_gloo():
 
 
 def test_bench_parent_refuses_more_ranks_than_gpus():
-    """`python bench.py --gpus N` without a launcher is a parent that only counts devices (it never initialises the GPU) and starts the
-    ranks as child processes; with fewer than N devices visible - none in the build container - it must exit non-zero and print no JSON
-    line: never a silent fall-back to fewer ranks (the N > 1 happy path is tests/test_bench_gpu.py)."""
+    """`python bench.py --gpus N` without a launcher is a parent that touches no GPU at all (it does not even count devices) and starts
+    the ranks as child processes; with fewer than N devices visible - none in the build container - every rank refuses, and the parent
+    relays that: non-zero exit, the ranks' message, no JSON line - never a silent fall-back to fewer ranks (the N > 1 happy path is
+    tests/test_bench_gpu.py)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -112,5 +113,5 @@ def test_bench_parent_refuses_more_ranks_than_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("BUSCA_BENCH_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "1", "--no-variants",
                         "--cpu-seconds", "0", "--latency-samples", "0"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
-    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert r.returncode != 0, (r.returncode, r.stderr[-500:])
     assert "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

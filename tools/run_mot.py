@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--tracker")
     ap.add_argument("--format", choices=["bytetrack", "strongsort"], default="bytetrack")
     ap.add_argument("--compare-with")
+    ap.add_argument("--trackeval", action="store_true", help="also score the written files with TrackEval's MOTChallenge2DBox evaluator (HOTA / CLEAR / Identity) "
+                                                              "when the package imports - the evaluator GHOST calls (adapters/GHOST/src/eval_track_eval.py:70)")
+    ap.add_argument("--assert-identical", action="store_true", help="with --compare-with: exit 1 unless every result file equals the reference run's byte for byte")
     ap.add_argument("--busca-thresh", type=float)
     ap.add_argument("--max-frames", type=int)
     ap.add_argument("--raw-probs", action="store_true", help="select_highest_candidate=False (thresholds the raw probability)")
@@ -78,9 +81,17 @@ def main():
         n = harness.run_sequence(seq, tracker, os.path.join(a.out, seq.name + ".txt"), fmt=a.format, max_frames=a.max_frames)
         print("rank %d: %s -> %d rows" % (rank, seq.name, n), file=sys.stderr)
     report = {"scores": harness.evaluate(a.out, [seqs[i] for i in mine]), "trackeval_available": harness.trackeval_available()}
+    if a.trackeval:
+        gt_root = a.synthetic if a.synthetic else a.data_root
+        te = harness.run_trackeval(a.out, [seqs[i] for i in mine], gt_root)
+        report["trackeval"] = te if te is not None else "TrackEval is not importable here: built-in CLEAR-MOT / IDF1 / HOTA restatements only"
     if a.compare_with:
         report["compare"] = harness.compare_runs(a.out, a.compare_with)
     print(json.dumps(report, indent=1))
+    if a.compare_with and a.assert_identical:
+        if not report["compare"]["all_identical"]:
+            print("run_mot: result files differ from the reference run", file=sys.stderr)
+            sys.exit(1)
 
 
 if __name__ == "__main__":
