@@ -542,3 +542,33 @@ def test_reid_weighted_batch_with_many_distinct_crops(ctx):
     full = m.forward(torch.from_numpy(uniq).cuda()[torch.from_numpy(inverse).cuda()]).cpu().numpy()
     first = np.concatenate([[0], np.cumsum(counts)[:-1]])
     assert np.abs(w - full[first]).max() <= 5e-3 and (w * full[first]).sum(1).min() >= 0.9998
+
+
+def test_reid_x3_large_batch_schedules_at_oracle_size(ctx):
+    """The two schedules the split-fp16 flavour switches to on large batches - BN3 statistics of layers 1-2 from the Gram matrix of conv3's
+    input (x3_gram_kernel) and the block tails of layers 3-4 formed by the NEXT conv1 while it stages (X3_MRG) - forced on at a batch the
+    oracle finishes in seconds (their thresholds put to zero through busca_set_option): same bar against the oracle as the default
+    schedule (5e-5), plain and with multiplicities, deterministic, and the default schedule is back bit for bit afterwards."""
+    from busca_amd.reid import ReIDEncoderHIP
+    from oracle import reid as oreid
+    sd = synth.reid_state_dict(3)
+    uniq = _crops(909, 5)
+    counts = np.array([3, 1, 2, 1, 4])
+    expanded = uniq[np.repeat(np.arange(5), counts)]
+    m = ReIDEncoderHIP(ctx, sd, precision="x3")
+    base = m.forward(uniq).cpu().numpy()
+    gmin, mmin = ctx.get_option("reid_x3_gram_min"), ctx.get_option("reid_x3_merge_in_min")
+    assert gmin > 5 * 3072 * 64 and mmin > 5 * 192 * 1024          # i.e. the default schedule above did NOT take them
+    ctx.set_option("reid_x3_gram_min", 0); ctx.set_option("reid_x3_merge_in_min", 0)
+    try:
+        a = m.forward(uniq).cpu().numpy()
+        assert np.array_equal(a, m.forward(uniq).cpu().numpy())
+        w = m.forward(uniq, weights=counts).cpu().numpy()
+    finally:
+        ctx.set_option("reid_x3_gram_min", gmin); ctx.set_option("reid_x3_merge_in_min", mmin)
+    assert np.array_equal(base, m.forward(uniq).cpu().numpy())
+    ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(uniq)).numpy()
+    assert np.abs(a - ref).max() <= 5e-5 and np.abs(a - base).max() <= 2e-5, (np.abs(a - ref).max(), np.abs(a - base).max())
+    refw = oreid.reid_forward(sd, oreid.crops_to_reid_input(expanded)).numpy()
+    first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    assert np.abs(w - refw[first]).max() <= 5e-5, np.abs(w - refw[first]).max()

@@ -1,0 +1,48 @@
+#!/bin/bash
+# Round-4 evidence (run through gpurun): kernel-trace stats of the bench legs + ReID passes (x3 and fp16) + the layer-wise DT shapes,
+# SQ counters and HBM traffic of the x3 ReID pass, HBM traffic of the layer-wise DT shapes, decision agreement.
+# Usage: bash tools/gpu_profiles_r04.sh [outdir] [part]      part: a = traces, b = counters, c = decision agreement (default: all)
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=${1:-gpurun_out/r04/prof}; PART=${2:-abc}; mkdir -p $O
+tr() { rocprofv3 --kernel-trace --stats --output-format csv -d $O/$1 -o t -- "${@:2}" > $O/$1.log 2>&1; python3 tools/kstats.py $O/$1 > $O/$1.stats.txt; }
+if [[ $PART == *a* ]]; then
+tr dt_f32_steps20 python3 bench.py --precision f32 --steps 20 --warmup 5 --cpu-seconds 0 --latency-samples 0 --no-variants --split-steps 0
+tr dt_f16_inflight16 python3 bench.py --precision f16 --inflight 16 --steps 320 --warmup 32 --cpu-seconds 0 --latency-samples 0 --no-variants --split-steps 0
+tr reid_x3_512 python3 tools/reid_bench.py 512 3 x3
+tr reid_x3_88 python3 tools/reid_bench.py 88 3 x3
+tr reid_f16_512 python3 tools/reid_bench.py 512 3 f16
+tr reid_f16_88 python3 tools/reid_bench.py 88 3 f16
+tr dtl_cfg5_f16 python3 tools/dt_cfg_bench.py 512 64 512 f16 5
+tr dtl_cfg4_f16 python3 tools/dt_cfg_bench.py 256 32 512 f16 5
+tr dtl_cfg4_f32 python3 tools/dt_cfg_bench.py 256 32 512 f32 5
+for N in 512 88; do python3 tools/timeline.py $(find $O/reid_x3_$N -name "*kernel_trace.csv" | head -1) preprocess -v > $O/reid_x3_${N}_timeline.txt 2>/dev/null; done
+python3 bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err
+fi
+if [[ $PART == *b* ]]; then
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $O/sq_reid_x3_512 -o p1 -- python3 tools/reid_bench.py 512 2 x3 > $O/sq_p1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/sq_reid_x3_512 -o p2 -- python3 tools/reid_bench.py 512 2 x3 > $O/sq_p2.log 2>&1
+python3 profiles/pmc_kernel_table.py $O/sq_reid_x3_512 > $O/reid_x3_512_sq_counters.txt 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $O/sq_dtl_cfg5 -o p1 -- python3 tools/dt_cfg_bench.py 512 64 512 f16 4 > $O/sq_dtl_p1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/sq_dtl_cfg5 -o p2 -- python3 tools/dt_cfg_bench.py 512 64 512 f16 4 > $O/sq_dtl_p2.log 2>&1
+python3 profiles/pmc_kernel_table.py $O/sq_dtl_cfg5 > $O/dtl_cfg5_sq_counters.txt 2>&1
+bash tools/pmc_traffic.sh $O/pmc_reid_x3_512 python3 tools/reid_bench.py 512 2 x3 > /dev/null 2>&1
+python3 profiles/pmc_traffic_summary.py $O/pmc_reid_x3_512 4 > $O/reid_x3_512_pmc_traffic.txt
+mkdir -p $O/pmc_dt
+while read KEY BT P D PREC; do
+  [ -z "$KEY" ] && continue
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_dt/$KEY -o fetch -- python3 tools/dt_cfg_bench.py $BT $P $D $PREC 4 > $O/pmc_dt/$KEY.fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_dt/$KEY -o write -- python3 tools/dt_cfg_bench.py $BT $P $D $PREC 4 > $O/pmc_dt/$KEY.write.log 2>&1
+done <<LIST
+dt_f32_F2_B128_P32_d512 256 32 512 f32
+dt_f16_F2_B128_P32_d512 256 32 512 f16
+dt_f16_F1_B512_P64_d512 512 64 512 f16
+dt_f32_F20_B32_P16_d256 640 16 256 f32
+LIST
+python3 tools/pmc_dt_traffic.py $O/pmc_dt > $O/pmc_dt_entries.json
+fi
+if [[ $PART == *c* ]]; then
+python3 tools/decision_agreement.py 2000 $O/decision_agreement.json > $O/decision_agreement.log 2>&1
+fi
+find $O -name "*.csv" -size +4M -delete
+ls $O | head -60
