@@ -298,7 +298,8 @@ def assoc_e2e(frames):
         out["multi_sequence_4x_lost8"] = e2e_sim.run_multi(4, 8, 60, 5, 512, "f16", frames)
     except Exception as e:
         out["multi_sequence_4x_lost8"] = {"error": repr(e)}
-    out["config"] = ("shipped model shape d=512 ff=1024 L=11 P=5, random weights, synthetic 1080p frames; default keys: f16 MFMA DT + fp16 ReID; "
+    out["config"] = ("shipped model shape d=512 ff=1024 L=11 P=5, random weights, synthetic 1080p frames; p50_crop_ms = the frame's two get_image_crops calls "
+                     "(detections + Kalman boxes: frame upload, crop kernel, lazy host copy enqueued) until the tracker's stream is done; default keys: f16 MFMA DT + fp16 ReID; "
                      "f32_* keys: float32 DT + exact-f32 ReID (reference arithmetic); x3_* keys: float32 DT + float32-equivalent ReID on split-fp16 MFMA")
     return out
 

@@ -66,6 +66,7 @@ class CropPool:
         self.slab_crops = int(slab_crops)
         self.max_slabs = max(1, int(budget_bytes) // (self.slab_crops * CROP_BYTES))
         self.slabs = []
+        self.slab_ptrs = []                 # data_ptr() of every slab (asked once, not per slot)
         self.free = []                      # (slab, index)
         self.live = OrderedDict()           # id -> weakref(Slot), allocation order = eviction order
         self.spilled = 0                    # crops moved to the host because the budget was reached
@@ -88,6 +89,7 @@ class CropPool:
     def _grow(self):
         t = torch.empty(self.slab_crops, CROP_H, CROP_W, 3, dtype=torch.uint8, device=self.device)
         self.slabs.append(t)
+        self.slab_ptrs.append(t.data_ptr())
         s = len(self.slabs) - 1
         self.free.extend((s, i) for i in range(self.slab_crops - 1, -1, -1))
 
@@ -113,10 +115,11 @@ class CropPool:
             else:
                 self._spill_oldest(n - len(self.free))
         out = []
+        free, live, ptrs, ref = self.free, self.live, self.slab_ptrs, weakref.ref
         for _ in range(n):
-            s, i = self.free.pop()
-            slot = Slot(self, s, i, self.slabs[s].data_ptr() + i * CROP_BYTES)
-            self.live[id(slot)] = weakref.ref(slot)
+            s, i = free.pop()
+            slot = Slot(self, s, i, ptrs[s] + i * CROP_BYTES)
+            live[id(slot)] = ref(slot)
             out.append(slot)
         self.peak_live = max(self.peak_live, len(self.live))
         return out

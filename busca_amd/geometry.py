@@ -74,14 +74,16 @@ def crop_gather(ctx, frame, boxes, want_u8=True, want_f16=False, dst_ptrs=None):
     rects = boxes.reshape(-1, 4) if boxes.dtype == np.int32 else box_extents(boxes)
     n = rects.shape[0]
     # extents (2 x int64 per box) and destination slots (1 x int64) in ONE host->device copy
-    meta = np.empty((n, 3), np.int64)
+    # ... staged in pinned memory (torch's caching host allocator) so the copy is asynchronous: a pageable source makes it a synchronous hipMemcpy
+    meta_t = torch.empty((max(n, 1), 3), dtype=torch.int64, pin_memory=True)[:n]
+    meta = meta_t.numpy()
     meta[:, :2] = np.ascontiguousarray(rects, dtype=np.int32).view(np.int64).reshape(n, 2)
     meta[:, 2] = np.ascontiguousarray(dst_ptrs, dtype=np.uint64).view(np.int64) if dst_ptrs is not None else 0
     H, W = frame.shape[:2]
     u8 = torch.empty(n, 384, 128, 3, dtype=torch.uint8, device=dev) if want_u8 else None
     f16 = torch.empty(n, 384, 128, 4, dtype=torch.float16, device=dev) if want_f16 else None
     if n:
-        packed = torch.from_numpy(meta).to(dev)                                  # [n][3] int64: (x1 y1 | x2 y2 | slot)
+        packed = meta_t.to(dev, non_blocking=True)                               # [n][3] int64: (x1 y1 | x2 y2 | slot)
         rects_t = packed[:, :2].contiguous()                                     # device-side repack: 32 bytes per box, no second PCIe copy
         dst_t = packed[:, 2].contiguous() if dst_ptrs is not None else None
         ctx.check(ctx.lib.busca_crop_gather_ex(ctx.h, frame.data_ptr(), H, W, frame.stride(0), rects_t.data_ptr(), n,
@@ -117,6 +119,8 @@ def gather_crops(ctx, src_ptrs):
     n = len(src_ptrs)
     out = torch.empty(n, 384, 128, 3, dtype=torch.uint8, device=dev)
     if n:
-        src = torch.from_numpy(np.ascontiguousarray(src_ptrs, dtype=np.uint64).view(np.int64)).to(dev)
+        stage = torch.empty(n, dtype=torch.int64, pin_memory=True)                # pinned staging: the upload is asynchronous
+        stage.numpy()[:] = np.ascontiguousarray(src_ptrs, dtype=np.uint64).view(np.int64)
+        src = stage.to(dev, non_blocking=True)
         ctx.check(ctx.lib.busca_gather_crops(ctx.h, src.data_ptr(), n, out.data_ptr(), _stream(ctx)))
     return out

@@ -1,7 +1,10 @@
 """Synthetic tracker scene for end-to-end measurements and tests: moving pedestrian-shaped boxes over synthetic
 frames, crops cut by `BUSCA.get_image_crops` (so track memories are device-resident), lost tracks with Kalman
 candidates - the caller contract of byte_tracker.py:367-397 / deep_sort tracker.py:129-189 without a real tracker."""
+import time
+
 import numpy as np
+import torch
 
 from . import synth
 
@@ -66,13 +69,22 @@ class SimScene:
     def step_inputs(self, n_lost):
         """One frame in which the first n_lost objects lose their detection: returns (lost tracks, detection objects,
         Kalman candidates) exactly as a tracker hands them to associate_embeddings."""
-        frame, boxes = self.next_frame()
+        return self.crop_inputs(*self.next_frame(), n_lost)
+
+    def crop_inputs(self, frame, boxes, n_lost):
+        """The tracker-side half of step_inputs for a frame already produced (next_frame): the two get_image_crops calls of an update - detections,
+        Kalman boxes of the lost tracks - and the objects built from them."""
         tlbr = boxes.copy()
         tlbr[:, 2:] += tlbr[:, :2]
         det_idx = np.arange(n_lost, self.n)
+        t0 = time.perf_counter()
         det_crops = self.model.get_image_crops(frame, tlbr[det_idx], normalize=False)
+        kal_crops = self.model.get_image_crops(frame, tlbr[:n_lost], normalize=False)
+        # the crops are in HBM when the tracker's stream is done; their host copy (lazy mode: a side stream into pinned memory) keeps flowing
+        # under whatever follows and is only waited for by a host read of the pixels
+        torch.cuda.current_stream().synchronize()
+        self.last_crop_calls_s = time.perf_counter() - t0            # the library's share of this method (the rest is this simulator's bookkeeping)
         dets = [SimTrack(boxes[i], det_crops[k]) for k, i in enumerate(det_idx)]
         lost = self.tracks[:n_lost]
-        kal_crops = self.model.get_image_crops(frame, tlbr[:n_lost], normalize=False)
         kalman = [SimTrack(boxes[i], kal_crops[i]) for i in range(n_lost)]
         return lost, dets, kalman

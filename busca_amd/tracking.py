@@ -274,10 +274,10 @@ def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False, hos
     pool = geometry.crop_pool(ctx)
     slots = pool.alloc(len(rects))
     ptrs = np.array([s.ptr for s in slots], dtype=np.uint64)
-    geometry.crop_gather(ctx, im, rects, want_u8=False, dst_ptrs=ptrs)
     if host_copy == "never":
+        geometry.crop_gather(ctx, im, rects, want_u8=False, dst_ptrs=ptrs)
         return DeviceCrops(slots)
-    packed = geometry.gather_crops(ctx, ptrs)                 # the batch as one contiguous device buffer (the slots need not be adjacent)
+    packed, _ = geometry.crop_gather(ctx, im, rects, want_u8=True, dst_ptrs=ptrs)    # the same launch also writes the batch as one contiguous buffer (the slots need not be adjacent)
     if host_copy == "eager":
         return DeviceBackedCrops(packed.cpu().numpy(), slots)
     dev = packed.device
