@@ -644,17 +644,17 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
             f.Xop = Xop; f.Oop = O; f.X = X; f.Xh = Xh; f.w_out = W.w_out; f.w1 = W.w1; f.w2 = W.w2; f.b_out = W.b_out; f.g1 = W.g1; f.be1 = W.be1;
             f.b1 = W.b1; f.b2 = W.b2; f.gamma = W.g2; f.beta = W.be2; f.M = (int)M; f.FF = FF; f.act = K.act;
             constexpr int DK = D >= 256 ? D : 256;
-            constexpr int BMF = (PREC == 1 || DK <= 256) ? 64 : 32;
-            constexpr size_t flds = (size_t)2 * BMF * (DK * ES + 16) + (size_t)2 * 8 * BMF * 4;
+            constexpr int BMF = DTLFfnGeom<PREC, DK>::BM;
+            constexpr size_t flds = DTLFfnGeom<PREC, DK>::LDS;
             TimedLaunch tl(c, s);
             if (ffn_mode == 2) {
                 auto kern = dtl_ffn_kernel<PREC, DK, true>;
                 { int rc = ensure_lds(c, (const void*)kern, flds); if (rc) return rc; }
-                hipLaunchKernelGGL(kern, dim3((unsigned)((M + BMF - 1) / BMF)), dim3(512), flds, s, f);
+                hipLaunchKernelGGL(kern, dim3((unsigned)((M + BMF - 1) / BMF)), dim3(64 * DTLFfnGeom<PREC, DK>::NWV), flds, s, f);
             } else {
                 auto kern = dtl_ffn_kernel<PREC, DK, false>;
                 { int rc = ensure_lds(c, (const void*)kern, flds); if (rc) return rc; }
-                hipLaunchKernelGGL(kern, dim3((unsigned)((M + BMF - 1) / BMF)), dim3(512), flds, s, f);
+                hipLaunchKernelGGL(kern, dim3((unsigned)((M + BMF - 1) / BMF)), dim3(64 * DTLFfnGeom<PREC, DK>::NWV), flds, s, f);
             }
             continue;
         }

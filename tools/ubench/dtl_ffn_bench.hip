@@ -2,6 +2,7 @@
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form tools/ubench/dtl_ffn_bench.hip -o tools/ubench/dtl_ffn_bench
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,9 +20,9 @@ static inline float frand() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; ret
 
 static void pack(const std::vector<float>& W, int N, int K, int prec, std::vector<unsigned char>& dst) {     // busca_hip.hip pack_matrix
     const int chunk = prec == 0 ? 16 : 32, sub = chunk / 4;
-    dst.resize((size_t)N * K * (prec == 0 ? 4 : 2));
+    dst.assign((size_t)(N / 16) * (K / chunk + DTL_TPAD) * 1024, 0);
     size_t off = 0;
-    for (int nt = 0; nt < N / 16; ++nt)
+    for (int nt = 0; nt < N / 16; ++nt, off += (size_t)DTL_TPAD * 1024)
         for (int kc = 0; kc < K / chunk; ++kc)
             for (int lane = 0; lane < 64; ++lane) {
                 const int a = lane & 15, kb = lane >> 4;
@@ -64,8 +65,8 @@ static void run(int M, int FF) {
     float* dH; CK(hipMalloc(&dH, (size_t)M * FF * 4)); CK(hipMemset(dH, 0, (size_t)M * FF * 4));
     DTLFfnArgs f{}; f.dbg_h = dH; f.Oop = dO; f.w_out = (const u32x4*)dwo; f.b_out = dbo; f.g1 = dg1; f.be1 = dbe1;
     f.Xop = PREC == 0 ? (const void*)dX : (const void*)dXh; f.X = dX; f.Xh = dXh; f.w1 = (const u32x4*)dw1; f.w2 = (const u32x4*)dw2; f.b1 = db1; f.b2 = db2; f.gamma = dg; f.beta = dbe; f.M = M; f.FF = FF; f.act = 0;
-    constexpr int BMF = (PREC == 1 || D <= 256) ? 64 : 32;
-    const size_t lds = (size_t)2 * BMF * (D * ES + 16) + (size_t)2 * 8 * BMF * 4;
+    constexpr int BMF = DTLFfnGeom<PREC, D>::BM;
+    const size_t lds = DTLFfnGeom<PREC, D>::LDS;
     CK(hipFuncSetAttribute((const void*)dtl_ffn_kernel<PREC, D, OUTPROJ, PFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms = 0;
@@ -73,10 +74,26 @@ static void run(int M, int FF) {
     for (int rep = 0; rep < 3; ++rep) {       // the kernel updates X in place: restore it every time
         CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dXh, Xh.data(), X.size() * 2, hipMemcpyHostToDevice));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((dtl_ffn_kernel<PREC, D, OUTPROJ, PFV>), dim3((M + BMF - 1) / BMF), dim3(512), lds, 0, f);
+        hipLaunchKernelGGL((dtl_ffn_kernel<PREC, D, OUTPROJ, PFV>), dim3((M + BMF - 1) / BMF), dim3(64 * DTLFfnGeom<PREC, D>::NWV), lds, 0, f);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
         CK(hipEventElapsedTime(&ms, e0, e1));
     }
+#ifdef DTL_FFN_TS
+    if (M > 20000) {        // phase breakdown of one more launch
+        const int nwg = std::min((M + BMF - 1) / BMF, 1024);
+        unsigned long long* dts; CK(hipMalloc(&dts, (size_t)1024 * 8 * 8 * 8)); CK(hipMemset(dts, 0, (size_t)1024 * 8 * 8 * 8));
+        f.ts = dts;
+        hipLaunchKernelGGL((dtl_ffn_kernel<PREC, D, OUTPROJ, PFV>), dim3((M + BMF - 1) / BMF), dim3(64 * DTLFfnGeom<PREC, D>::NWV), lds, 0, f);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> ts((size_t)1024 * 64); CK(hipMemcpy(ts.data(), dts, ts.size() * 8, hipMemcpyDeviceToHost));
+        double ph[8] = {0}; for (int w = 0; w < nwg * DTLFfnGeom<PREC, D>::NWV; ++w) for (int k = 0; k < 8; ++k) ph[k] += (double)ts[(size_t)w * 8 + k];
+        double tot = 0; for (int k = 0; k < 8; ++k) tot += ph[k];
+        const double nwv = (double)nwg * DTLFfnGeom<PREC, D>::NWV;
+        printf("   phases per wave (100 MHz ticks): stage %.0f | out-proj GEMM %.0f | +res, LN1, x1 stores %.0f | FFN1 GEMMs %.0f | act + stores + barrier %.0f | FFN2 GEMMs %.0f | barrier %.0f | +res, LN2, stores %.0f | total %.0f\n",
+               ph[0] / nwv, ph[1] / nwv, ph[2] / nwv, ph[3] / nwv, ph[4] / nwv, ph[5] / nwv, ph[6] / nwv, ph[7] / nwv, tot / nwv);
+        f.ts = nullptr; hipFree(dts);
+    }
+#endif
     std::vector<float> out(X.size());
     CK(hipMemcpy(out.data(), dX, X.size() * 4, hipMemcpyDeviceToHost));
     // reference (sampled rows), operands rounded as the kernel rounds them
