@@ -118,9 +118,9 @@ def _compare(name, kal_e, kal_f, win_e, win_f, margin_e, dprob):
 
 
 SHARP_GAIN = 12.0       # decoder gain of the second run (probabilities straddle 0.5)
-FLAVOURS = (("default: float32 Decision Transformer + fp16 ReID", "f32", "f16"),
+FLAVOURS = (("opt-in fast ReID (the default until round 3): float32 Decision Transformer + fp16 ReID", "f32", "f16"),
             ("fastest: f16-operand Decision Transformer + fp16 ReID", "f16", "f16"),
-            ("reference tolerance: float32 Decision Transformer + float32-equivalent ReID on split-fp16 MFMA (x3)", "f32", "x3"))
+            ("default: float32 Decision Transformer + float32-equivalent ReID on split-fp16 MFMA (x3)", "f32", "x3"))
 
 
 def run(steps=2000, seed=2026, verbose=False, decoder_gain=1.0):
