@@ -42,8 +42,10 @@ class Slot:
         """uint8 [384,128,3] host copy (device -> host on first use when the crop only lived in HBM)."""
         if self.host is None and self.host_src is not None:
             frame, k = self.host_src            # the frame's asynchronous device->host copy: wait for its event, then it is a plain view
-            self.host = frame.rows()[k]
+            rows = frame.rows()                 # (None once that copy has been retired: the slot itself is read below)
             self.host_src = None
+            if rows is not None:
+                self.host = rows[k]
         if self.host is None:
             if not self.ptr:
                 raise RuntimeError("crop slot lost both its device and its host copy")       # cannot happen: spill copies first

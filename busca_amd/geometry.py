@@ -73,22 +73,39 @@ def crop_gather(ctx, frame, boxes, want_u8=True, want_f16=False, dst_ptrs=None):
     boxes = np.asarray(boxes)
     rects = boxes.reshape(-1, 4) if boxes.dtype == np.int32 else box_extents(boxes)
     n = rects.shape[0]
-    # extents (2 x int64 per box) and destination slots (1 x int64) in ONE host->device copy
-    # ... staged in pinned memory (torch's caching host allocator) so the copy is asynchronous: a pageable source makes it a synchronous hipMemcpy
-    meta_t = torch.empty((max(n, 1), 3), dtype=torch.int64, pin_memory=True)[:n]
-    meta = meta_t.numpy()
-    meta[:, :2] = np.ascontiguousarray(rects, dtype=np.int32).view(np.int64).reshape(n, 2)
-    meta[:, 2] = np.ascontiguousarray(dst_ptrs, dtype=np.uint64).view(np.int64) if dst_ptrs is not None else 0
+    # The box extents (4 x int32 per box) and the destination slots (1 x int64) are NOT copied to the device: they are written into PINNED host
+    # memory, which the GPU maps at the same address, and the kernel reads its few KB straight from there (an asynchronous 3 KB copy costs
+    # ~70 us of host time per call on this stack, two device-side repack kernels another ~20 us).  The table stays referenced (with an event
+    # behind the launch) until 32 later calls have been issued and its own launch has completed.
     H, W = frame.shape[:2]
     u8 = torch.empty(n, 384, 128, 3, dtype=torch.uint8, device=dev) if want_u8 else None
     f16 = torch.empty(n, 384, 128, 4, dtype=torch.float16, device=dev) if want_f16 else None
     if n:
-        packed = meta_t.to(dev, non_blocking=True)                               # [n][3] int64: (x1 y1 | x2 y2 | slot)
-        rects_t = packed[:, :2].contiguous()                                     # device-side repack: 32 bytes per box, no second PCIe copy
-        dst_t = packed[:, 2].contiguous() if dst_ptrs is not None else None
-        ctx.check(ctx.lib.busca_crop_gather_ex(ctx.h, frame.data_ptr(), H, W, frame.stride(0), rects_t.data_ptr(), n,
-                                               _lib.ptr(dst_t), _lib.ptr(u8), _lib.ptr(f16), _stream(ctx)))
+        table = torch.empty(n * 3, dtype=torch.int64, pin_memory=True)           # [n][2] int64 = [n][4] int32 extents, then [n] int64 slot addresses
+        tab = table.numpy()
+        tab[:2 * n] = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1).view(np.int64)
+        if dst_ptrs is not None:
+            tab[2 * n:] = np.ascontiguousarray(dst_ptrs, dtype=np.uint64).view(np.int64)
+        base = table.data_ptr()
+        ctx.check(ctx.lib.busca_crop_gather_ex(ctx.h, frame.data_ptr(), H, W, frame.stride(0), base, n,
+                                               (base + 16 * n) if dst_ptrs is not None else None, _lib.ptr(u8), _lib.ptr(f16), _stream(ctx)))
+        _keep_until_done(ctx, table, dev)
     return u8, f16
+
+
+def _keep_until_done(ctx, host_tensor, dev, depth=32):
+    """Keep a pinned host tensor a launched kernel reads alive: torch's caching host allocator would hand the block out again as soon as the
+    last Python reference dies, and it only knows about uses by its own copies."""
+    from collections import deque
+    q = getattr(ctx, "_pinned_in_flight", None)
+    if q is None:
+        q = ctx._pinned_in_flight = deque()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    q.append((host_tensor, ev))
+    while len(q) > depth:
+        _, old = q.popleft()
+        old.synchronize()                                                        # long complete in practice: one query
 
 
 def _frame_on_device(ctx, frame, dev):

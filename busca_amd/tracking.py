@@ -1,6 +1,8 @@
 """Proposal-side geometry with the reference's names and semantics (busca/tracking.py), computed by the
 HIP kernels behind the C-ABI (busca_pairwise / busca_crop_gather).  Inputs and outputs are host numpy
 arrays exactly like the reference; there is no CPU implementation here."""
+import os
+
 import numpy as np
 import torch
 
@@ -152,17 +154,26 @@ class FrameHostCopy:
     """The host bytes of one get_image_crops call, on their way: the crops were written into pool slots on the GPU; one
     asynchronous device->host copy of all of them into PINNED memory runs on a side stream, and the first HOST read of any
     of the crops waits for its event (usually long past).  A tracker that never looks at pixels never waits."""
-    __slots__ = ("host", "event", "_np")
+    __slots__ = ("host", "event", "_np", "expired")
 
     def __init__(self, host, event):
-        self.host, self.event, self._np = host, event, None
+        self.host, self.event, self._np, self.expired = host, event, None, False
 
     def rows(self):
+        """uint8 [n,384,128,3] host view of the batch, or None once the copy has been retired (the crops then read their pool slot)."""
+        if self.expired:
+            return None
         if self._np is None:
             self.event.synchronize()
             self._np = self.host.numpy()
             self.event = None
         return self._np
+
+    def retire(self):
+        """Give the pinned buffer back (views already handed out keep their memory alive through numpy's base reference)."""
+        if self.event is not None:
+            self.event.synchronize()
+        self.host, self.event, self._np, self.expired = None, None, None, True
 
 
 class DeviceCrop(np.lib.mixins.NDArrayOperatorsMixin):
@@ -242,6 +253,8 @@ def box_extents(bboxes):
 
 
 _COPY_STREAMS = {}
+_HOST_COPIES = {}                       # device index -> the FrameHostCopy objects of the last _HOST_COPY_CALLS lazy calls
+_HOST_COPY_CALLS = max(1, int(os.environ.get("BUSCA_AMD_HOST_COPY_CALLS", "8")))
 
 
 def _copy_stream(dev):
@@ -292,6 +305,12 @@ def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False, hos
     frame = FrameHostCopy(host, ev)
     for k, sl in enumerate(slots):
         sl.host_src = (frame, k)
+    # the pinned copies of the last few calls only: a copy every live crop of a frame kept alive made pinned memory grow by 22 MB per frame for as
+    # long as track memories held crops (a fresh hipHostMalloc per call, ~0.3 ms); crops older than that read their pool slot on demand instead
+    ring = _HOST_COPIES.setdefault(dev.index or 0, [])
+    ring.append(frame)
+    while len(ring) > _HOST_COPY_CALLS:
+        ring.pop(0).retire()
     return DeviceCrops(slots)
 
 

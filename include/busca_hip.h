@@ -198,7 +198,9 @@ int busca_crop_gather(busca_ctx* ctx, const uint8_t* frame, int32_t H, int32_t W
  *          to the caller's float64 values (`tlbr * scale`); rounding them on the host in float64 keeps the cut-out extent
  *          identical where a float32 copy of the box would land on the other side of an integer.
  *   dst_u8 dev u64 [n] or NULL: when given, crop i (147 456 bytes, u8 BGR) is written to address dst_u8[i] (a slot of the
- *          device-resident crop pool, busca_amd/crop_pool.py) instead of out_u8 + i*147456; out_u8 may then be NULL.
+ *          device-resident crop pool, busca_amd/crop_pool.py) IN ADDITION to out_u8 + i*147456 when out_u8 is given; out_u8 may be NULL.
+ * rects and dst_u8 may also point into PINNED host memory the GPU maps (hipHostMalloc): one thread per crop reads them once and the
+ * kernels work on device copies - the caller then needs no host-to-device copy, but must keep the tables unchanged until the launch has run.
  */
 int busca_crop_gather_ex(busca_ctx* ctx, const uint8_t* frame, int32_t H, int32_t W, int32_t stride, const int32_t* rects,
                          int32_t n, const uint64_t* dst_u8, uint8_t* out_u8, void* out_f16, void* stream);

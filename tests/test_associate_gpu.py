@@ -244,6 +244,30 @@ def test_device_only_crops(model):
         model.device_only_crops = False
 
 
+def test_lazy_host_copies_are_bounded_and_old_crops_still_read_right(model):
+    """Lazy mode keeps the pinned host copy of the last few get_image_crops calls only (tracking._HOST_COPY_CALLS): a crop whose frame copy has been
+    retired hands out the same pixels from its pool slot, a view taken BEFORE the retirement stays valid, and the retired buffers are really released
+    (the number of live copies does not grow with the sequence)."""
+    from busca_amd import tracking
+    model.pinned_numpy = True
+    frame = synth.randint_u8(9, "frame", (540, 960, 3))
+    boxes = np.array([[40 + 25 * i, 30 + 4 * i, 100 + 25 * i, 250 + 4 * i] for i in range(12)], np.float32)
+    eager = np.asarray(tracking.get_image_crops(frame, boxes, normalize=False, ctx=model._ctx, host_copy="eager"))
+    first = model.get_image_crops(frame, boxes, normalize=False)
+    early_view = np.asarray(first[3])                            # materialised while the copy is alive: a view into its pinned buffer
+    assert first[5].slot.host is None and first[5].slot.host_src is not None
+    keep = [first]
+    for k in range(tracking._HOST_COPY_CALLS + 3):               # later calls push the first copy out of the ring
+        keep.append(model.get_image_crops(np.roll(frame, 3 * (k + 1), axis=1), boxes, normalize=False))
+    dev = model._ctx.device
+    assert len(tracking._HOST_COPIES[dev]) == tracking._HOST_COPY_CALLS
+    assert first[5].slot.host_src[0].expired and first[5].slot.host_src[0].host is None
+    assert np.array_equal(np.asarray(first[5]), eager[5])        # read from the slot
+    assert np.array_equal(early_view, eager[3]) and np.array_equal(np.asarray(first[3]), eager[3])
+    assert np.array_equal(np.asarray(keep[-1][2]), np.asarray(tracking.get_image_crops(np.roll(frame, 3 * len(keep[1:]), axis=1), boxes, normalize=False,
+                                                                                      ctx=model._ctx, host_copy="eager"))[2])
+
+
 def test_two_models_on_one_gpu_do_not_share_weights():
     """Two BUSCA objects (different shapes and weights) used alternately give what each gives alone; the same for two
     DecisionTransformerHIP / ReIDEncoderHIP handles that share one context."""
