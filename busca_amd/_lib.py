@@ -44,6 +44,7 @@ SIGNATURES = {
     "busca_duplicate_masks": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, C.c_double, _vp, _vp, _vp]),
     "busca_crop_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "busca_crop_gather_ex": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "busca_crop_gather_sized": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     "busca_gather_crops": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "busca_reid_forward_ex": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "busca_reid_forward_w": (C.c_int, [_vp, _vp, _i32, _vp, _vp, C.c_double, _vp, _vp]),

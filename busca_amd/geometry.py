@@ -93,6 +93,25 @@ def crop_gather(ctx, frame, boxes, want_u8=True, want_f16=False, dst_ptrs=None):
     return u8, f16
 
 
+def crop_gather_sized(ctx, frame, boxes, out_w, out_h):
+    """Crops of an arbitrary output size (busca_crop_gather_sized): u8 [n, out_h, out_w, 3] on the GPU."""
+    from .tracking import box_extents
+    dev = _dev(ctx)
+    frame = _frame_on_device(ctx, frame, dev)
+    assert frame.dtype == torch.uint8 and frame.dim() == 3 and frame.shape[2] == 3
+    boxes = np.asarray(boxes.detach().cpu().numpy() if torch.is_tensor(boxes) else boxes)
+    rects = boxes.reshape(-1, 4) if boxes.dtype == np.int32 else box_extents(boxes)
+    n = rects.shape[0]
+    out = torch.empty(n, int(out_h), int(out_w), 3, dtype=torch.uint8, device=dev)
+    if n:
+        table = torch.empty(n * 2, dtype=torch.int64, pin_memory=True)
+        table.numpy()[:] = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1).view(np.int64)
+        H, W = frame.shape[:2]
+        ctx.check(ctx.lib.busca_crop_gather_sized(ctx.h, frame.data_ptr(), H, W, frame.stride(0), table.data_ptr(), n, int(out_h), int(out_w), out.data_ptr(), _stream(ctx)))
+        _keep_until_done(ctx, table, dev)
+    return out
+
+
 def _keep_until_done(ctx, host_tensor, dev, depth=32):
     """Keep a pinned host tensor a launched kernel reads alive: torch's caching host allocator would hand the block out again as soon as the
     last Python reference dies, and it only knows about uses by its own copies."""

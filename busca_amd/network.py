@@ -545,11 +545,9 @@ class BUSCA:
 
     def get_image_crops(self, image, bboxes, output_size=None, normalize=True):
         """busca/network.py:492-507: all boxes of a frame cut, padded and resized on the GPU in one launch."""
-        if output_size is not None and tuple(output_size) != (self.expected_image_size[1], self.expected_image_size[0]):
-            raise NotImplementedError("only the ReID crop size 128x384 is built")
         self._sync()
         return tracking.get_image_crops(image, bboxes, normalize=normalize, ctx=self._ctx,
-                                        host_copy="never" if self.device_only_crops else self.crop_host_copy)
+                                        host_copy="never" if self.device_only_crops else self.crop_host_copy, output_size=output_size)
 
 
 class ReID_Encoder(_ReIDFacade):

@@ -264,7 +264,7 @@ def _copy_stream(dev):
     return _COPY_STREAMS[key]
 
 
-def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False, host_copy=None):
+def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False, host_copy=None, output_size=None):
     """All crops of one frame in one launch: u8 BGR [N,384,128,3] (float32 normalised if `normalize`).
     With normalize=False every crop is written into a slot of the device crop pool and the returned crops remember
     their slot.  `host_copy` says what happens to the HOST bytes of those crops (147 KB each - the bulk of this call when it
@@ -274,9 +274,15 @@ def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False, hos
       "eager" wait for it: a real uint8 ndarray (`DeviceBackedCrops`) - for callers that need ndarray instances;
       "never" (`device_only=True`) no copy at all; a host read copies that one crop back synchronously."""
     rects = box_extents(bboxes)
+    sized = output_size is not None and tuple(int(v) for v in output_size) != (128, 384)
     if len(rects) == 0:
-        return np.zeros([0, 128, 384, 3])            # the reference's (transposed) empty shape, network.py:503
+        return np.zeros([0, int(output_size[0]), int(output_size[1]), 3]) if sized else np.zeros([0, 128, 384, 3])     # the reference's (transposed) empty shape, network.py:503
     ctx = ctx or geometry.default_context()
+    if sized:
+        # `output_size` = (width, height) as cv2.resize takes it (tracking.py:71): plain host arrays [N, height, width, 3], no pool slots -
+        # only the 384 x 128 crops are ReID inputs
+        u8 = geometry.crop_gather_sized(ctx, im, rects, int(output_size[0]), int(output_size[1])).cpu().numpy()
+        return normalize_crops(u8) if normalize else u8
     if normalize:
         u8, _ = geometry.crop_gather(ctx, im, rects, want_u8=True)
         return normalize_crops(u8.cpu().numpy())
@@ -315,10 +321,8 @@ def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False, hos
 
 
 def get_bbox_crop(im, bbox_real_scale, output_size=(128, 384), normalize=True, ghost_normalize=True, ctx=None):
-    """Single crop (busca/tracking.py:62-78).  Only the 128x384 ReID geometry is built."""
-    if tuple(output_size) != (128, 384):
-        raise NotImplementedError("only output_size=(128, 384) is supported")
-    crop = get_image_crops(im, [bbox_real_scale], normalize=False, ctx=ctx)[0]
+    """Single crop (busca/tracking.py:62-78); `output_size` = (width, height) as cv2.resize takes it."""
+    crop = np.asarray(get_image_crops(im, [bbox_real_scale], normalize=False, ctx=ctx, output_size=output_size)[0])
     if normalize:
         crop = crop.astype(np.float32) / 255.0
         crop -= _PIXEL_MEAN

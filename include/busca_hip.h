@@ -205,6 +205,13 @@ int busca_crop_gather(busca_ctx* ctx, const uint8_t* frame, int32_t H, int32_t W
 int busca_crop_gather_ex(busca_ctx* ctx, const uint8_t* frame, int32_t H, int32_t W, int32_t stride, const int32_t* rects,
                          int32_t n, const uint64_t* dst_u8, uint8_t* out_u8, void* out_f16, void* stream);
 /*
+ * Crops of any output size (busca/tracking.py:62-71 `get_bbox_crop(..., output_size=(w, h))`, busca/network.py:492-507 `output_size`): the
+ * same cut-out + pad + cv2.INTER_LINEAR restatement as busca_crop_gather_ex, u8 BGR [n, out_h, out_w, 3] only.  rects as in
+ * busca_crop_gather_ex (device or pinned host).  The ReID path itself only ever uses 384 x 128 (busca_crop_gather[_ex]).
+ */
+int busca_crop_gather_sized(busca_ctx* ctx, const uint8_t* frame, int32_t H, int32_t W, int32_t stride, const int32_t* rects,
+                            int32_t n, int32_t out_h, int32_t out_w, uint8_t* out_u8, void* stream);
+/*
  * Index gather of track memories (busca/network.py:247-279 `_get_track_mem` + the np.array(...) stacking of :313,383):
  * out dev u8 [n,384,128,3]; crop i is copied from device address src[i] (dev u64 [n]); src[i] == 0 gives an all-zero crop
  * (incomplete memory :306, padded candidate :354).

@@ -111,6 +111,37 @@ def test_crop_gather_bit_exact(ctx):
     assert (gn[..., 3] == 0).all()
 
 
+@pytest.mark.parametrize("out_wh", [(64, 192), (96, 96), (128, 256), (50, 37), (256, 768)])
+def test_crops_of_other_output_sizes_bit_exact(ctx, out_wh):
+    """`get_image_crops(output_size=(w, h))` / `get_bbox_crop(output_size=...)` for sizes other than the ReID crop (busca/network.py:492-507,
+    busca/tracking.py:62-78): the generic kernel against the oracle's cut-out + OpenCV fixed-point bilinear restatement, bit for bit - including the
+    copy (box extent == output size), the exact 2x shrink, padded, tiny, empty and fully-outside boxes; normalised crops and the empty-list shape too."""
+    from busca_amd import tracking
+    from oracle import geometry as og
+    w, h = out_wh
+    fr = _frame(5, 540, 960)
+    boxes = np.array([
+        [100.3, 50.2, 180.9, 300.7],
+        [-20.5, -30.0, 60.2, 200.0],
+        [900.0, 400.0, 1000.0, 600.0],
+        [10.0, 10.0, 10.0 + w, 10.0 + h],             # exactly the output size -> copy
+        [200.0, 20.0, 200.0 + 2 * w, 20.0 + 2 * h],   # exactly twice -> the 2x2 area path (clipped at the frame edge for the large sizes)
+        [5.5, 5.5, 6.2, 6.1],
+        [2000.0, 2000.0, 2100.0, 2200.0],
+        [50.0, 60.0, 50.0, 60.0],
+        [400.0, 100.0, 1000.0, 539.5],
+    ], dtype=np.float64)
+    got = tracking.get_image_crops(fr, boxes, normalize=False, ctx=ctx, output_size=(w, h))
+    assert type(got) is np.ndarray and got.dtype == np.uint8 and got.shape == (len(boxes), h, w, 3)
+    for i, bx in enumerate(boxes):
+        ref = og.get_bbox_crop(fr, bx, output_size=(w, h))
+        assert np.array_equal(got[i], ref), "crop %d differs (max %d)" % (i, np.abs(got[i].astype(int) - ref.astype(int)).max())
+    one = tracking.get_bbox_crop(fr, boxes[0], output_size=(w, h), normalize=True, ctx=ctx)
+    assert one.dtype == np.float32 and np.array_equal(one, og.get_bbox_crop(fr, boxes[0], output_size=(w, h), normalize=True))
+    assert np.array_equal(tracking.get_image_crops(fr, boxes[:2], normalize=True, ctx=ctx, output_size=(w, h)), og.normalize_bgr(got[:2]))
+    assert tracking.get_image_crops(fr, [], normalize=False, ctx=ctx, output_size=(w, h)).shape == (0, w, h, 3)      # the reference's transposed empty shape
+
+
 def test_crop_gather_empty(ctx):
     from busca_amd import geometry as G
     u8, _ = G.crop_gather(ctx, _frame(1, 64, 64), np.zeros((0, 4), np.float32))
