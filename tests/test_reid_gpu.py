@@ -567,7 +567,18 @@ def test_reid_x3_large_batch_schedules_at_oracle_size(ctx):
     finally:
         ctx.set_option("reid_x3_gram_min", gmin); ctx.set_option("reid_x3_merge_in_min", mmin)
     assert np.array_equal(base, m.forward(uniq).cpu().numpy())
+    # ... and layer 1's fused tails with the next bottleneck's conv1 inside (X3_MERGE_C1, on by default) against the two-kernel schedule: the conv's raw
+    # output is the same to the bit, its BatchNorm statistics are summed in another order
+    assert ctx.get_option("reid_x3_fuse_c1") == 1
+    ctx.set_option("reid_x3_fuse_c1", 0)
+    try:
+        plain = m.forward(uniq).cpu().numpy()
+        plain_w = m.forward(uniq, weights=counts).cpu().numpy()
+    finally:
+        ctx.set_option("reid_x3_fuse_c1", 1)
+    assert np.abs(plain - base).max() <= 2e-5 and np.abs(plain_w - m.forward(uniq, weights=counts).cpu().numpy()).max() <= 2e-5
     ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(uniq)).numpy()
+    assert np.abs(plain - ref).max() <= 5e-5
     assert np.abs(a - ref).max() <= 5e-5 and np.abs(a - base).max() <= 2e-5, (np.abs(a - ref).max(), np.abs(a - base).max())
     refw = oreid.reid_forward(sd, oreid.crops_to_reid_input(expanded)).numpy()
     first = np.concatenate([[0], np.cumsum(counts)[:-1]])

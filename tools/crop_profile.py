@@ -53,3 +53,21 @@ for fr in frames:
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+
+# the same two calls inside the simulated tracker (track memories hold their crops: no slot is released, the pool grows, old host copies retire)
+print("---- inside SimScene.crop_inputs (tracks keep their crops) ----")
+ts = []
+pr2 = cProfile.Profile()
+for f in range(40):
+    fr, bx = scene.next_frame()
+    torch.cuda.synchronize()
+    if f >= 10:
+        pr2.enable()
+    lost_t, dets, kal = scene.crop_inputs(fr, bx, lost)
+    if f >= 10:
+        pr2.disable()
+        ts.append(scene.last_crop_calls_s)
+    for t, d in zip(scene.tracks[lost:], dets):          # detected tracks take the new crop, as a tracker's update does
+        t.update(d.tlwh, d.images_mem[0])
+print("crop calls inside the scene: p50 %.3f ms, p90 %.3f ms" % (1e3 * float(np.median(ts)), 1e3 * float(np.percentile(ts, 90))))
+pstats.Stats(pr2).sort_stats("tottime").print_stats(14)
