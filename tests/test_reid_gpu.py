@@ -577,6 +577,17 @@ def test_reid_x3_large_batch_schedules_at_oracle_size(ctx):
     finally:
         ctx.set_option("reid_x3_fuse_c1", 1)
     assert np.abs(plain - base).max() <= 2e-5 and np.abs(plain_w - m.forward(uniq, weights=counts).cpu().numpy()).max() <= 2e-5
+    # ... and the stride-1 3x3 convs of layers 1-2 staged once per kernel row (ROW3, on by default; 2 = layers 3-4 too on 64-pixel tiles) against the
+    # tap-by-tap schedule: the same products, summed chunk-major instead of tap-major where a conv has more than 64 input channels
+    assert ctx.get_option("reid_x3_row3") == 1
+    for mode in (0, 2):
+        ctx.set_option("reid_x3_row3", mode)
+        try:
+            alt = m.forward(uniq).cpu().numpy()
+            alt_w = m.forward(uniq, weights=counts).cpu().numpy()
+        finally:
+            ctx.set_option("reid_x3_row3", 1)
+        assert np.abs(alt - base).max() <= 2e-5 and np.abs(alt_w - plain_w).max() <= 2e-5, (mode, np.abs(alt - base).max())
     ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(uniq)).numpy()
     assert np.abs(plain - ref).max() <= 5e-5
     assert np.abs(a - ref).max() <= 5e-5 and np.abs(a - base).max() <= 2e-5, (np.abs(a - ref).max(), np.abs(a - base).max())
