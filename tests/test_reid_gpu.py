@@ -588,6 +588,14 @@ def test_reid_x3_large_batch_schedules_at_oracle_size(ctx):
         finally:
             ctx.set_option("reid_x3_row3", 1)
         assert np.abs(alt - base).max() <= 2e-5 and np.abs(alt_w - plain_w).max() <= 2e-5, (mode, np.abs(alt - base).max())
+    # ... and the stem with its input rows staged once per tile as an LDS halo (STEMH, default) against the tap-by-tap stem: the same products in the same order
+    assert ctx.get_option("reid_x3_stem_halo") == 1
+    ctx.set_option("reid_x3_stem_halo", 0)
+    try:
+        alt = m.forward(uniq).cpu().numpy()
+    finally:
+        ctx.set_option("reid_x3_stem_halo", 1)
+    assert np.abs(alt - base).max() <= 2e-5, np.abs(alt - base).max()
     ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(uniq)).numpy()
     assert np.abs(plain - ref).max() <= 5e-5
     assert np.abs(a - ref).max() <= 5e-5 and np.abs(a - base).max() <= 2e-5, (np.abs(a - ref).max(), np.abs(a - base).max())
