@@ -596,6 +596,17 @@ def test_reid_x3_large_batch_schedules_at_oracle_size(ctx):
     finally:
         ctx.set_option("reid_x3_stem_halo", 1)
     assert np.abs(alt - base).max() <= 2e-5, np.abs(alt - base).max()
+    # ... and that stem filled straight from the u8 crops through the byte table (default) against the same stem fed from the normalised float copy:
+    # the table holds exactly the preprocess kernel's values, so the features are bit-identical - with a padding crop (zero_norm) in the batch too
+    assert ctx.get_option("reid_x3_stem_u8") == 1
+    zn = torch.tensor([0, 0, 1, 0, 0], dtype=torch.uint8, device="cuda")
+    with_bytes = m.forward(uniq, zero_norm=zn).cpu().numpy()
+    ctx.set_option("reid_x3_stem_u8", 0)
+    try:
+        assert np.array_equal(with_bytes, m.forward(uniq, zero_norm=zn).cpu().numpy())
+        assert np.array_equal(base, m.forward(uniq).cpu().numpy())
+    finally:
+        ctx.set_option("reid_x3_stem_u8", 1)
     ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(uniq)).numpy()
     assert np.abs(plain - ref).max() <= 5e-5
     assert np.abs(a - ref).max() <= 5e-5 and np.abs(a - base).max() <= 2e-5, (np.abs(a - ref).max(), np.abs(a - base).max())
