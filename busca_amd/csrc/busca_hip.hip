@@ -158,7 +158,7 @@ static int* reid_option_field(ReidState& R, const std::string& n) {
 }
 static bool* reid_option_flag(ReidState& R, const std::string& n) {
     struct { const char* name; bool* p; } tab[] = {{"reid_halo", &R.halo}, {"reid_fuse_c1", &R.fuse_c1}, {"reid_fuse_c1_small", &R.fuse_c1_small},
-                                                   {"reid_stats2", &R.two_launch_stats}, {"reid_pipe_all", &R.pipe_all}, {"reid_wd_all", &R.wd_all}, {"reid_x3_gram", &R.x3_gram}, {"reid_x3_merge_in", &R.x3_merge_in}, {"reid_x3_fuse_c1", &R.x3_fuse_c1}, {"reid_x3_stem_halo", &R.x3_stem_halo}, {"reid_x3_stem_u8", &R.x3_stem_u8}};
+                                                   {"reid_stats2", &R.two_launch_stats}, {"reid_pipe_all", &R.pipe_all}, {"reid_wd_all", &R.wd_all}, {"reid_x3_gram", &R.x3_gram}, {"reid_x3_merge_in", &R.x3_merge_in}, {"reid_x3_fuse_c1", &R.x3_fuse_c1}, {"reid_x3_stem_halo", &R.x3_stem_halo}, {"reid_x3_stem_u8", &R.x3_stem_u8}, {"reid_x3_stem_pool", &R.x3_stem_pool}};
     for (auto& e : tab) if (n == e.name) return e.p;
     return nullptr;
 }

@@ -60,7 +60,7 @@ const char* busca_build_info(void);
  * forwards): "reid_gram", "reid_halo", "reid_fuse_c1", "reid_fuse_c1_layers", "reid_fuse_c1_small", "reid_fuse_ds_layers", "reid_splitk_blocks",
  * "reid_halo_min", "reid_halo_half", "reid_halo_wpx", "reid_halo_wpx_min", "reid_gram_min", "reid_direct_rows", "reid_stats2", "reid_kwave_blocks",
  * "reid_kwave_halo", "reid_kwave_nw", "reid_kwave_pt", "reid_glds_min", "reid_glds_bm", "reid_wd_min", "reid_wd_all", "reid_pipe_min", "reid_pipe_half",
- * "reid_pipe_all", "reid_x3_merge_layers", "reid_x3_half", "reid_x3_gram", "reid_x3_gram_min", "reid_x3_merge_in", "reid_x3_merge_in_min", "reid_x3_fuse_c1", "reid_x3_fuse_c1_min", "reid_x3_narrow3", "reid_x3_row3", "reid_x3_stem_halo", "reid_x3_stem_u8" (meanings: DESIGN.md section 5).  Before weights are loaded: BUSCA_ENOWEIGHTS. */
+ * "reid_pipe_all", "reid_x3_merge_layers", "reid_x3_half", "reid_x3_gram", "reid_x3_gram_min", "reid_x3_merge_in", "reid_x3_merge_in_min", "reid_x3_fuse_c1", "reid_x3_fuse_c1_min", "reid_x3_narrow3", "reid_x3_row3", "reid_x3_stem_halo", "reid_x3_stem_u8", "reid_x3_stem_pool" (meanings: DESIGN.md section 5).  Before weights are loaded: BUSCA_ENOWEIGHTS. */
 int busca_set_option(busca_ctx* ctx, const char* name, int32_t value);
 int busca_get_option(busca_ctx* ctx, const char* name, int32_t* value);
 

@@ -607,6 +607,16 @@ def test_reid_x3_large_batch_schedules_at_oracle_size(ctx):
         assert np.array_equal(base, m.forward(uniq).cpu().numpy())
     finally:
         ctx.set_option("reid_x3_stem_u8", 1)
+    # ... and the stem that writes the 3x3 / stride-2 max pool of its raw output (times sign(gamma)) in two parts, with layer 1's first conv1 and downsample
+    # conv staging relu(bn(max(P, Q above))) (X3_POOL / X3_POOLIN, default), against raw map + pooling pass: the pool commutes with the monotone
+    # BatchNorm + ReLU, so the features are the same to the bit
+    assert ctx.get_option("reid_x3_stem_pool") == 1
+    ctx.set_option("reid_x3_stem_pool", 0)
+    try:
+        assert np.array_equal(base, m.forward(uniq).cpu().numpy())
+        assert np.array_equal(with_bytes, m.forward(uniq, zero_norm=zn).cpu().numpy())
+    finally:
+        ctx.set_option("reid_x3_stem_pool", 1)
     ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(uniq)).numpy()
     assert np.abs(plain - ref).max() <= 5e-5
     assert np.abs(a - ref).max() <= 5e-5 and np.abs(a - base).max() <= 2e-5, (np.abs(a - ref).max(), np.abs(a - base).max())
