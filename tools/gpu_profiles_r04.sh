@@ -16,7 +16,7 @@ tr reid_f16_88 python3 tools/reid_bench.py 88 3 f16
 tr dtl_cfg5_f16 python3 tools/dt_cfg_bench.py 512 64 512 f16 5
 tr dtl_cfg4_f16 python3 tools/dt_cfg_bench.py 256 32 512 f16 5
 tr dtl_cfg4_f32 python3 tools/dt_cfg_bench.py 256 32 512 f32 5
-for N in 512 88; do python3 tools/timeline.py $(find $O/reid_x3_$N -name "*kernel_trace.csv" | head -1) preprocess -v > $O/reid_x3_${N}_timeline.txt 2>/dev/null; done
+for N in 512 88; do python3 tools/timeline.py $(find $O/reid_x3_$N -name "*kernel_trace.csv" | head -1) "conv_x3_kernel<2, 2, 2, 4, 2, 7" -v > $O/reid_x3_${N}_timeline.txt 2>/dev/null; done
 python3 bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err
 fi
 if [[ $PART == *b* ]]; then
