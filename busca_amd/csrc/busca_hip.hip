@@ -29,6 +29,7 @@
 #include "reid_pipe.hip.inc"
 #include "reid_f32.hip.inc"
 #include "reid_x3.hip.inc"
+#include "reid_x3p.hip.inc"
 #include "dt_tiled.hip.inc"
 #include "ecc_kernel.hip.inc"
 
@@ -152,7 +153,7 @@ static int* reid_option_field(ReidState& R, const std::string& n) {
         {"reid_fuse_ds_layers", &R.fuse_ds_layers}, {"reid_fuse_c1_layers", &R.fuse_c1_layers}, {"reid_kwave_blocks", &R.kwave_blocks},
         {"reid_kwave_halo", &R.kwave_halo_blocks}, {"reid_kwave_nw", &R.kwave_nw}, {"reid_kwave_pt", &R.kwave_pt}, {"reid_glds_min", &R.glds_min_tiles},
         {"reid_glds_bm", &R.glds_bm}, {"reid_wd_min", &R.wd_min_tiles}, {"reid_pipe_min", &R.pipe_min_tiles}, {"reid_pipe_half", &R.pipe_half_blocks},
-        {"reid_x3_merge_layers", &R.x3_merge_layers}, {"reid_x3_half", &R.x3_half_blocks}, {"reid_x3_gram_min", &R.x3_gram_min}, {"reid_x3_merge_in_min", &R.x3_merge_in_min}, {"reid_x3_fuse_c1_min", &R.x3_fuse_c1_min}, {"reid_x3_narrow3", &R.x3_narrow3}, {"reid_x3_row3", &R.x3_row3}};
+        {"reid_x3_merge_layers", &R.x3_merge_layers}, {"reid_x3_half", &R.x3_half_blocks}, {"reid_x3_gram_min", &R.x3_gram_min}, {"reid_x3_merge_in_min", &R.x3_merge_in_min}, {"reid_x3_fuse_c1_min", &R.x3_fuse_c1_min}, {"reid_x3_narrow3", &R.x3_narrow3}, {"reid_x3_row3", &R.x3_row3}, {"reid_x3_ptail", &R.x3_ptail_min}};
     for (auto& e : tab) if (n == e.name) return e.p;
     return nullptr;
 }

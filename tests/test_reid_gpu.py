@@ -623,3 +623,31 @@ def test_reid_x3_large_batch_schedules_at_oracle_size(ctx):
     refw = oreid.reid_forward(sd, oreid.crops_to_reid_input(expanded)).numpy()
     first = np.concatenate([[0], np.cumsum(counts)[:-1]])
     assert np.abs(w - refw[first]).max() <= 5e-5, np.abs(w - refw[first]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [5, 44])
+def test_reid_x3_persistent_tails_are_bit_identical(ctx, n):
+    """Round 5: the fused block tails of layers 1-2 as PERSISTENT workgroups (x3_ptail_kernel, reid_x3p.hip.inc: weights in registers, the next
+    half tile's rows prefetched under the current one's products) against the one-shot kernels (option reid_x3_ptail = 0): the same arithmetic
+    in the same order, so the features are equal to the bit - plain and with multiplicities (resnet.py:116-128, network.py:553-556)."""
+    from busca_amd.reid import ReIDEncoderHIP
+    sd = synth.reid_state_dict(3)
+    crops = _crops(4242, n)
+    counts = 1 + (np.arange(n) * 7) % 4
+    m = ReIDEncoderHIP(ctx, sd, precision="x3")
+    dflt = ctx.get_option("reid_x3_ptail")
+    assert dflt > 0
+    try:
+        ctx.set_option("reid_x3_ptail", 0)
+        one_shot = m.forward(crops).cpu().numpy()
+        one_shot_w = m.forward(crops, weights=counts).cpu().numpy()
+        ctx.set_option("reid_x3_ptail", 1)               # every tail of layers 1-2 on persistent workgroups, whatever the batch size
+        pers = m.forward(crops).cpu().numpy()
+        assert np.array_equal(pers, m.forward(crops).cpu().numpy())
+        pers_w = m.forward(crops, weights=counts).cpu().numpy()
+    finally:
+        ctx.set_option("reid_x3_ptail", dflt)
+    assert np.array_equal(one_shot, pers)
+    assert np.array_equal(one_shot_w, pers_w)
+    assert np.array_equal(m.forward(crops).cpu().numpy(), pers)          # the default schedule (persistent from 512 work items up) too
