@@ -193,7 +193,7 @@ def config_leg(ctx, dev, name, B, L, P, d, precision, F, steps, seed=7):
             "value": steps / el, "unit": "steps/s", "steps": steps, "ms_per_step": el / steps * 1e3, "steps_in_flight_per_launch": F,
             "path": "fused (one kernel per call)" if fused else "layer-wise (%d kernels per call)" % round(timing[1] / max(1, timing[2])),
             "roofline": roofline_obj(precision, B, L, P, d, ff, timing, el / calls * 1e3,
-                                     kernel="dt_fused_kernel" if fused else "dtl_gemm_kernel + dtl_attention_kernel (whole forward)")}
+                                     kernel="dt_fused_kernel" if fused else "dt_bucket_ids + dtl_gemm<EMBED> + 4 x (dtl_qkv_attn + dtl_ffn) + dtl_decoder (whole forward, every launch bracketed)")}
 
 
 def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None, reid_precision="f16"):
@@ -267,40 +267,92 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None, reid_precision="
 def assoc_e2e(frames):
     """Simulated tracker frame (tools/e2e_sim.py): crops cut on the GPU, device-resident track memory, centre distances,
     BUSCA.associate_embeddings on the SHIPPED model shape (d=512, L=11, P=5; config/*/*/*.yml) - the metric's
-    'p50 assoc latency'."""
+    'p50 assoc latency'.  The UNPREFIXED keys are what a user gets by default (busca_amd.network.BUSCA: float32 Decision Transformer +
+    float32-equivalent x3 ReID); `f16_*` = the opt-in fast flavours (fp16 ReID + f16 DT), `f32_*` = exact-f32 ReID + f32 DT."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gc
     import e2e_sim
     out = {}
+    keys = ("p50_assoc_latency_ms", "p50_crop_ms", "p50_center_distance_ms", "busca_frames_per_s", "device_resident_crops", "precision", "reid_precision")
     for lost, objs in ((32, 150), (8, 60)):
-        r = e2e_sim.run(lost, objs, 5, 512, "f16", frames, verbose=False)
-        out["lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "p50_center_distance_ms",
-                                                                          "busca_frames_per_s", "device_resident_crops")}
-    import gc
-    gc.collect(); torch.cuda.empty_cache()      # the previous scenes' models / crop pools go away before the next one is timed
-    try:        # the reference's own arithmetic: exact-f32 ReID + f32 Decision Transformer (the flavour with <= 1e-3 parity)
+        r = e2e_sim.run(lost, objs, 5, 512, frames=frames, verbose=False)            # library defaults: precision f32, reid_precision x3
+        out["lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in keys}
+        gc.collect(); torch.cuda.empty_cache()      # the previous scenes' models / crop pools go away before the next one is timed
+    try:        # opt-in fast flavours: fp16 ReID + f16 Decision Transformer (moves probabilities by up to 0.03, profiles/r04_decision_agreement.json)
+        for lost, objs in ((32, 150), (8, 60)):
+            r = e2e_sim.run(lost, objs, 5, 512, "f16", frames, verbose=False, reid_precision="f16")
+            out["f16_lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in keys}
+            gc.collect(); torch.cuda.empty_cache()
+    except Exception as e:
+        out["f16_lost32_dets118"] = {"error": repr(e)}
+    try:        # the reference's own arithmetic: exact-f32 ReID + f32 Decision Transformer
         for lost, objs in ((32, 150), (8, 60)):
             r = e2e_sim.run(lost, objs, 5, 512, "f32", max(5, frames // 2), verbose=False, reid_precision="f32")
             out["f32_lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in ("p50_assoc_latency_ms", "busca_frames_per_s", "precision", "reid_precision")}
             gc.collect(); torch.cuda.empty_cache()
     except Exception as e:
         out["f32_lost32_dets118"] = {"error": repr(e)}
-    try:        # float32-equivalent ReID on split-fp16 MFMA + f32 Decision Transformer: the reference's tolerance at a fraction of the exact flavour's cost
-        for lost, objs in ((32, 150), (8, 60)):
-            r = e2e_sim.run(lost, objs, 5, 512, "f32", max(5, frames // 2), verbose=False, reid_precision="x3")
-            out["x3_lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in ("p50_assoc_latency_ms", "busca_frames_per_s", "precision", "reid_precision")}
-            gc.collect(); torch.cuda.empty_cache()
-    except Exception as e:
-        out["x3_lost32_dets118"] = {"error": repr(e)}
-    r = e2e_sim.run(8, 60, 5, 512, "f16", frames, verbose=False, device_only_crops=True)     # opt-in: crops never copied back to the host
-    out["lost8_dets52_device_only_crops"] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "busca_frames_per_s")}
+    r = e2e_sim.run(8, 60, 5, 512, frames=frames, verbose=False, device_only_crops=True)     # opt-in: crops never copied back to the host (default flavour)
+    out["lost8_dets52_device_only_crops"] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "busca_frames_per_s", "precision", "reid_precision")}
     gc.collect(); torch.cuda.empty_cache()
-    try:        # several trackers on one GPU: the steps of one frame interval through the StepBatcher (one DT launch)
-        out["multi_sequence_4x_lost8"] = e2e_sim.run_multi(4, 8, 60, 5, 512, "f16", frames)
+    try:        # several trackers on one GPU: the steps of one frame interval through the StepBatcher (one DT launch), default flavour
+        out["multi_sequence_4x_lost8"] = e2e_sim.run_multi(4, 8, 60, 5, 512, frames=frames)
     except Exception as e:
         out["multi_sequence_4x_lost8"] = {"error": repr(e)}
     out["config"] = ("shipped model shape d=512 ff=1024 L=11 P=5, random weights, synthetic 1080p frames; p50_crop_ms = the frame's two get_image_crops calls "
-                     "(detections + Kalman boxes: frame upload, crop kernel, lazy host copy enqueued) until the tracker's stream is done; default keys: f16 MFMA DT + fp16 ReID; "
-                     "f32_* keys: float32 DT + exact-f32 ReID (reference arithmetic); x3_* keys: float32 DT + float32-equivalent ReID on split-fp16 MFMA")
+                     "(detections + Kalman boxes: ONE frame upload inside an explicit model.frame(img) scope, crop kernel, lazy host copy enqueued) until the tracker's stream is done; "
+                     "UNPREFIXED keys = library defaults: float32 DT + float32-equivalent x3 ReID (split-fp16 MFMA); f16_* keys: opt-in f16 MFMA DT + fp16 ReID; "
+                     "f32_* keys: float32 DT + exact-f32 ReID (reference arithmetic)")
+    return out
+
+
+def hbm_kernels(ctx, dev):
+    """The HBM-bound kernels of the path (crop gather K1, pairwise matrices + top-P K10/K11, track-memory gather) at tracker sizes:
+    algorithmic bytes / kernel time (HIP events around the launches on the launch stream, busca_timing_*) against the 8 TB/s peak.  At these sizes
+    every one of them is launch-latency-bound (tens of KB to tens of MB per launch), which is what the fractions say; rocprof summaries of the same
+    launches: profiles/r05_hbm_kernels_*."""
+    from busca_amd import geometry
+    lib, h = ctx.lib, ctx.h
+    rng = np.random.default_rng(5)
+
+    def timed(fn, reps=20):
+        fn(); torch.cuda.synchronize(dev)
+        lib.busca_timing_read(h, None, None, 1); lib.busca_timing_enable(h, 1)
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        avg, n = C.c_double(0), C.c_int64(0)
+        lib.busca_timing_read(h, C.byref(avg), C.byref(n), 1); lib.busca_timing_enable(h, 0)
+        return avg.value * n.value / reps            # ms per call (sum over the call's bracketed launches)
+
+    def entry(kernel, workload, nbytes, ms):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else float("nan")
+        return {"kernel": kernel, "workload": workload, "algorithmic_bytes": int(nbytes), "kernel_us": ms * 1e3, "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                "frac": gbs / 8000.0, "bound": "hbm"}
+
+    out = {}
+    # K1 crop gather: 150 boxes of a 1080p frame (the detections + Kalman boxes of a 32-lost / 118-detection frame)
+    frame = torch.from_numpy(synth.randint_u8(5, "frame", (1080, 1920, 3))).to(dev)
+    hh = rng.uniform(80, 320, 150); ww = hh * rng.uniform(0.3, 0.5, 150)
+    x = rng.uniform(0, 1920 - 170, 150); y = rng.uniform(0, 1080 - 330, 150)
+    tlbr = np.stack([x, y, x + ww, y + hh], 1)
+    ext = np.stack([np.floor(tlbr[:, 0]), np.floor(tlbr[:, 1]), np.ceil(tlbr[:, 2]), np.ceil(tlbr[:, 3])], 1)
+    src_bytes = float(((ext[:, 2] - ext[:, 0]) * (ext[:, 3] - ext[:, 1]) * 3).sum())
+    out["crop_gather_150_boxes_1080p"] = entry("crop_fill_kernel + crop_resize_kernel", "150 boxes of a 1080p frame -> u8 [150,384,128,3]",
+                                               src_bytes + 150 * 147456, timed(lambda: geometry.crop_gather(ctx, frame, tlbr, want_u8=True)))
+    # track-memory gather: 864 crops (32 lost x (11 memory + 16 candidate) slots) out of a resident batch
+    res = torch.from_numpy(synth.randint_u8(6, "res", (256, 384, 128, 3))).to(dev)
+    ptrs = (res.data_ptr() + rng.integers(0, 256, 864).astype(np.uint64) * np.uint64(147456)).astype(np.uint64)
+    out["crop_ptr_gather_864_crops"] = entry("crop_ptr_gather_kernel", "864 crops of 147 456 B gathered by address", 2 * 864 * 147456, timed(lambda: geometry.gather_crops(ctx, ptrs)))
+    # K10 / K11 pairwise centre distance + top-P
+    for nA, nB, P in ((128, 150, 32), (300, 1000, 16)):
+        a = torch.from_numpy(rng.uniform(0, 1000, (nA, 4))).to(dev); b = torch.from_numpy(rng.uniform(0, 1000, (nB, 4))).to(dev)
+        a[:, 2:] += a[:, :2]; b[:, 2:] += b[:, :2]
+        out["pairwise_center_%dx%d" % (nA, nB)] = entry("pairwise_kernel", "centre distance %d x %d float64" % (nA, nB), (nA + nB) * 32 + nA * nB * 8,
+                                                        timed(lambda: geometry.pairwise(ctx, a, b, 0)))
+        dist = geometry.pairwise(ctx, a, b, 0)
+        out["topk_rows_%dx%d_P%d" % (nA, nB, P)] = entry("topk_rows_kernel", "%d smallest of each of %d rows of %d float64" % (P, nA, nB), nA * nB * 8 + nA * P * 4,
+                                                         timed(lambda: geometry.topk_rows(ctx, dist, P)))
     return out
 
 
@@ -548,20 +600,38 @@ def main():
         try:        # BASELINE configs[3] as a FULL step (crops cut on the GPU, 1 408 + 4 096-crop BatchNorm batches, DT at T = 79)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import cfg4_step
-            cfgs["cfg4_full_step"] = cfg4_step.run(3, "f16")
-            cfgs["cfg4_full_step_expanded_batch"] = cfg4_step.run(3, "f16", dedup=False)
+            cfgs["cfg4_full_step"] = cfg4_step.run(3, "f32", reid_precision="x3")               # library defaults (x3 ReID + f32 DT)
+            cfgs["cfg4_full_step_f16"] = cfg4_step.run(3, "f16", reid_precision="f16")          # opt-in fast flavours
+            cfgs["cfg4_full_step_f16_expanded_batch"] = cfg4_step.run(3, "f16", dedup=False, reid_precision="f16")
         except Exception as e:
             cfgs["cfg4_full_step"] = {"error": repr(e)}
+        try:
+            result["hbm_kernels"] = hbm_kernels(ctx, dev)
+        except Exception as e:
+            result["hbm_kernels"] = {"error": repr(e)}
         if args.full_steps > 0:
-            dt16 = r2.model if other == "f16" else DTRunner(ctx, sd, "f16", tens, B, L, P, 1, dev).model
-            result["full_step"] = full_step(ctx, dt16, B, L, P, args.full_steps, dev)
-            result["full_step_tracker_like_candidates"] = full_step(ctx, dt16, B, L, P, args.full_steps, dev, n_det=118)
+            from busca_amd.dt import DecisionTransformerHIP
+            # UNPREFIXED `full_step` = the library's default flavour: float32-EQUIVALENT ReID on the fp16 matrix cores (BUSCA_PREC_F16X3: same parity bars as the
+            # exact flavour, tests/test_reid_gpu.py EXACT_FLAVOURS) + the f32 Decision Transformer.  Its own context: a busca_ctx holds one ReID weight set.
+            try:
+                ctx3 = _lib.Context(dev_index)
+                dt3 = DecisionTransformerHIP(ctx3, sd, activation="relu", fake_bbox_f64=True, precision="f32")
+                result["full_step"] = full_step(ctx3, dt3, B, L, P, args.full_steps, dev, reid_precision="x3")
+                result["full_step_tracker_like_candidates"] = full_step(ctx3, dt3, B, L, P, args.full_steps, dev, n_det=118, reid_precision="x3")
+                ctx3.close()
+            except Exception as e:
+                result["full_step"] = {"error": repr(e)}
+            # opt-in fast flavours: fp16 ReID + f16 Decision Transformer
+            try:
+                dt16 = r2.model if other == "f16" else DTRunner(ctx, sd, "f16", tens, B, L, P, 1, dev).model
+                result["full_step_f16"] = full_step(ctx, dt16, B, L, P, args.full_steps, dev)
+                result["full_step_f16_tracker_like_candidates"] = full_step(ctx, dt16, B, L, P, args.full_steps, dev, n_det=118)
+            except Exception as e:
+                result["full_step_f16"] = {"error": repr(e)}
             # the same step in the REFERENCE's arithmetic: exact-f32 ReID convs (<= 1e-4 against the reference's own features) +
-            # the f32 Decision Transformer, priced against the f32 MFMA peak.  Its own context: a busca_ctx holds one ReID weight set.
+            # the f32 Decision Transformer, priced against the f32 MFMA peak
             try:
                 ctx32 = _lib.Context(dev_index)
-                dt32 = run.model if args.precision == "f32" else r2.model
-                from busca_amd.dt import DecisionTransformerHIP
                 dt32 = DecisionTransformerHIP(ctx32, sd, activation="relu", fake_bbox_f64=True, precision="f32")
                 n32 = max(2, args.full_steps // 2)
                 result["full_step_f32"] = full_step(ctx32, dt32, B, L, P, n32, dev, reid_precision="f32")
@@ -569,17 +639,6 @@ def main():
                 ctx32.close()
             except Exception as e:
                 result["full_step_f32"] = {"error": repr(e)}
-            # ... and in float32-EQUIVALENT arithmetic on the fp16 matrix cores (BUSCA_PREC_F16X3 ReID: same parity bars as the exact
-            # flavour, tests/test_reid_gpu.py EXACT_FLAVOURS) + the f32 Decision Transformer
-            try:
-                ctx3 = _lib.Context(dev_index)
-                from busca_amd.dt import DecisionTransformerHIP
-                dt3 = DecisionTransformerHIP(ctx3, sd, activation="relu", fake_bbox_f64=True, precision="f32")
-                result["full_step_x3"] = full_step(ctx3, dt3, B, L, P, args.full_steps, dev, reid_precision="x3")
-                result["full_step_x3_tracker_like_candidates"] = full_step(ctx3, dt3, B, L, P, args.full_steps, dev, n_det=118, reid_precision="x3")
-                ctx3.close()
-            except Exception as e:
-                result["full_step_x3"] = {"error": repr(e)}
     if rank == 0:
         if args.cpu_seconds > 0:
             one = {k: v[:B] for k, v in big.items()}

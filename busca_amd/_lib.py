@@ -119,6 +119,13 @@ class Context:
         return int(v.value)
 
     def close(self):
+        # host-side attachments of busca_amd.geometry (frame scope, pinned tables still referenced behind their launches, crop pool)
+        self._frame_scope = None
+        q = getattr(self, "_pinned_in_flight", None)
+        if q:
+            for _, ev in q:
+                ev.synchronize()
+            q.clear()
         if getattr(self, "h", None) is not None and self.h.value:
             self.lib.busca_ctx_destroy(self.h)
             self.h = _vp()

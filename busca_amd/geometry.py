@@ -127,26 +127,50 @@ def _keep_until_done(ctx, host_tensor, dev, depth=32):
         old.synchronize()                                                        # long complete in practice: one query
 
 
+def begin_frame(ctx, frame):
+    """Upload `frame` (u8 [H,W,3] host array) ONCE for every crop call of one tracker update.  Adapters cut crops from the same host frame several
+    times per update (detections of both confidence bands, Kalman boxes - adapters/ByteTrack/yolox/tracker/byte_tracker.py:280-282; StrongSORT once
+    per detection, deep_sort/tracker.py:126).  The scope is EXPLICIT: between begin_frame and end_frame a crop call whose `image` IS this object
+    (identity; the scope holds a reference, so the id cannot be recycled) reuses the upload, and the caller promises not to edit the array inside the
+    scope.  Without a scope every call uploads the array it is given - what busca/network.py:492-507 does with the live array - so no result ever
+    depends on a guess about whether two host buffers hold the same pixels (rounds 2-4 guessed with a sparse pixel fingerprint: removed)."""
+    dev = _dev(ctx)
+    arr = np.asarray(frame)
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    ctx._frame_scope = (frame, t, ev)
+    return t
+
+
+def end_frame(ctx):
+    ctx._frame_scope = None
+
+
+class frame_scope:
+    """`with geometry.frame_scope(ctx, frame): ...` = begin_frame / end_frame."""
+
+    def __init__(self, ctx, frame):
+        self.ctx, self.frame = ctx, frame
+
+    def __enter__(self):
+        begin_frame(self.ctx, self.frame)
+        return self
+
+    def __exit__(self, *exc):
+        end_frame(self.ctx)
+        return False
+
+
 def _frame_on_device(ctx, frame, dev):
-    """The frame as a contiguous cuda u8 tensor.  Adapters cut crops from the SAME host frame several times per update (detections of
-    both confidence bands, Kalman boxes - adapters/ByteTrack/yolox/tracker/byte_tracker.py:280-282; StrongSORT once per detection,
-    deep_sort/tracker.py:126): the upload (6 MB for 1080p) is done once and reused while the host array is the same object with the same
-    buffer and a sparse fingerprint of its pixels is unchanged (in-place edits between two calls are caught unless they miss every
-    sampled pixel; BUSCA_FRAME_CACHE=0 uploads every time)."""
+    """The frame as a contiguous cuda u8 tensor: the scope's upload when `frame` is the scoped object, else a fresh upload of the live array."""
     if torch.is_tensor(frame):
         return frame.to(dev).contiguous()
-    import os
-    arr = np.asarray(frame)
-    if os.environ.get("BUSCA_FRAME_CACHE", "1") == "0" or arr.ndim != 3:
-        return torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
-    sy, sx = max(1, arr.shape[0] // 29), max(1, arr.shape[1] // 43)
-    key = (id(frame), arr.__array_interface__["data"][0], arr.shape, arr.strides, hash(arr[::sy, ::sx].tobytes()))
-    cached = getattr(ctx, "_frame_cache", None)
-    if cached is not None and cached[0] == key:
-        return cached[1]
-    t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
-    ctx._frame_cache = (key, t)
-    return t
+    scope = getattr(ctx, "_frame_scope", None)
+    if scope is not None and scope[0] is frame:
+        torch.cuda.current_stream(dev).wait_event(scope[2])          # the upload may have been enqueued on another stream
+        return scope[1]
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(frame))).to(dev)
 
 
 def gather_crops(ctx, src_ptrs):

@@ -166,6 +166,10 @@ class LiteTracker:
         _Track._next_id = 1
 
     def update(self, frame, dets):
+        with self.model.frame(frame):               # both get_image_crops calls of this update cut from ONE upload of the frame
+            return self._update(frame, dets)
+
+    def _update(self, frame, dets):
         from scipy.optimize import linear_sum_assignment
         a = self.args
         self.frame_id += 1

@@ -78,8 +78,9 @@ class SimScene:
         tlbr[:, 2:] += tlbr[:, :2]
         det_idx = np.arange(n_lost, self.n)
         t0 = time.perf_counter()
-        det_crops = self.model.get_image_crops(frame, tlbr[det_idx], normalize=False)
-        kal_crops = self.model.get_image_crops(frame, tlbr[:n_lost], normalize=False)
+        with self.model.frame(frame):                # one upload for both calls (explicit scope: an integrated adapter's `with model.frame(img):` around update)
+            det_crops = self.model.get_image_crops(frame, tlbr[det_idx], normalize=False)
+            kal_crops = self.model.get_image_crops(frame, tlbr[:n_lost], normalize=False)
         # the crops are in HBM when the tracker's stream is done; their host copy (lazy mode: a side stream into pinned memory) keeps flowing
         # under whatever follows and is only waited for by a host read of the pixels
         torch.cuda.current_stream().synchronize()

@@ -169,3 +169,44 @@ def test_detection_coverage_bit_exact(ctx):
     empty = tracking.get_detection_coverage((H, W, 3), [], [], ctx=ctx)
     assert empty["area_covered"] == 0.0 and empty["bbox_areas"] == []
     assert tracking.is_reliable((H, W, 3), tracks[:50], (3.0, 0.0), ctx=ctx) in (True, False)
+
+
+def test_crops_always_come_from_the_live_frame(ctx):
+    """busca/network.py:492-507 cuts from the array it is given.  Rounds 2-4 cached the uploaded frame behind object identity + a sparse pixel
+    fingerprint, which an edit between two calls could miss (and a recycled id / buffer address could alias): the cache is gone.  An edit of one
+    8 x 8 block between two calls on the SAME array - placed so that a 29 x 43 sampling grid would have missed it - and a freshly allocated array
+    (the allocator is free to hand the old buffer out again) both give the new pixels; only inside an explicit `begin_frame` scope is an upload reused
+    (adapters/ByteTrack/yolox/tracker/byte_tracker.py:280-282 cuts three times from one frame)."""
+    from busca_amd import geometry, tracking
+    H, W = 1080, 1920
+    frame = synth.randint_u8(77, "frame", (H, W, 3))
+    box = np.array([[100.0, 100.0, 164.0, 292.0]])           # covers the edited block
+    first = np.asarray(tracking.get_image_crops(frame, box, normalize=False, ctx=ctx, host_copy="eager"))
+    sy, sx = H // 29, W // 43
+    y0, x0 = 3 * sy + 5, 3 * sx + 3                           # strictly between grid lines: rows 116..123, columns 135..142
+    assert y0 % sy >= 5 and (y0 + 7) % sy < sy and x0 % sx >= 3 and (x0 + 7) // sx == x0 // sx
+    frame[y0:y0 + 8, x0:x0 + 8] = 255 - frame[y0:y0 + 8, x0:x0 + 8]
+    second = np.asarray(tracking.get_image_crops(frame, box, normalize=False, ctx=ctx, host_copy="eager"))
+    want = np.asarray(tracking.get_image_crops(frame.copy(), box, normalize=False, ctx=ctx, host_copy="eager"))
+    assert not np.array_equal(first, second) and np.array_equal(second, want)
+    # a new array on (very likely) the old address, other pixels
+    addr = frame.__array_interface__["data"][0]
+    del frame
+    fresh = np.empty((H, W, 3), np.uint8)
+    fresh[:] = synth.randint_u8(78, "frame", (H, W, 3))
+    third = np.asarray(tracking.get_image_crops(fresh, box, normalize=False, ctx=ctx, host_copy="eager"))
+    assert np.array_equal(third, np.asarray(tracking.get_image_crops(fresh.copy(), box, normalize=False, ctx=ctx, host_copy="eager")))
+    assert not np.array_equal(third, second), (addr, fresh.__array_interface__["data"][0])
+    # the explicit scope: one upload, reused by identity until end_frame; other arrays are still uploaded
+    geometry.begin_frame(ctx, fresh)
+    try:
+        up = ctx._frame_scope[1]
+        assert geometry._frame_on_device(ctx, fresh, up.device) is up
+        inside = np.asarray(tracking.get_image_crops(fresh, box, normalize=False, ctx=ctx, host_copy="eager"))
+        other = fresh.copy(); other[100:300, 100:170] = 7
+        assert geometry._frame_on_device(ctx, other, up.device) is not up
+        assert not np.array_equal(np.asarray(tracking.get_image_crops(other, box, normalize=False, ctx=ctx, host_copy="eager")), inside)
+    finally:
+        geometry.end_frame(ctx)
+    assert np.array_equal(inside, third)
+    assert getattr(ctx, "_frame_scope", None) is None

@@ -19,10 +19,10 @@ from busca_amd.reid import ReIDEncoderHIP
 REID_GFLOP_PER_CROP = 8.01
 
 
-def run(steps=3, precision="f16", B=128, L=11, P=32, n_det=160, d=512, check=False, seed=7, dedup=True):
+def run(steps=3, precision="f16", B=128, L=11, P=32, n_det=160, d=512, check=False, seed=7, dedup=True, reid_precision="f16"):
     dev = torch.device("cuda", 0)
     ctx = _lib.Context(0)
-    reid = ReIDEncoderHIP(ctx, synth.reid_state_dict(seed))
+    reid = ReIDEncoderHIP(ctx, synth.reid_state_dict(seed), precision=reid_precision)
     sd = synth.dt_state_dict(seed, d=d, ff=2 * d)
     dt = DecisionTransformerHIP(ctx, sd, precision=precision)
     dt.reserve(B, L, P)
@@ -76,10 +76,11 @@ def run(steps=3, precision="f16", B=128, L=11, P=32, n_det=160, d=512, check=Fal
     el = (time.perf_counter() - t0) / steps
     crops = B * (L + P)
     computed = B * L + (len(np.unique(order)) if dedup else B * P)
-    res = {"workload": "cfg4 full step: %d lost x %d proposals x d%d, %d + %d crop slots cut/gathered on the GPU (%d detections), ReID (fp16) + DT (%s)%s"
-                       % (B, P, d, B * L, B * P, n_det, precision, "; repeated candidate crops computed once, statistics weighted" if dedup else "; expanded candidate batch"),
+    res = {"workload": "cfg4 full step: %d lost x %d proposals x d%d, %d + %d crop slots cut/gathered on the GPU (%d detections), ReID (%s) + DT (%s)%s"
+                       % (B, P, d, B * L, B * P, n_det, reid_precision, precision, "; repeated candidate crops computed once, statistics weighted" if dedup else "; expanded candidate batch"),
            "value": 1.0 / el, "unit": "steps/s", "ms_per_step": el * 1e3, "crops_per_step": crops, "crops_computed": computed, "steps": steps,
-           "reid_tflops_executed": computed * REID_GFLOP_PER_CROP / el / 1e3, "frac_of_f16_mfma_peak_executed": computed * REID_GFLOP_PER_CROP / el / 1e3 / 2500.0}
+           "reid_tflops_executed": computed * REID_GFLOP_PER_CROP / el / 1e3, "frac_of_f16_mfma_peak_executed": computed * REID_GFLOP_PER_CROP / el / 1e3 / 2500.0,
+           "dtype": reid_precision, "dt_dtype": precision}
     if check:
         res["_out"] = {k: v.cpu().numpy() for k, v in out.items()}
         res["_feat"] = (mf.cpu().numpy(), cf.cpu().numpy())
