@@ -24,8 +24,6 @@
 #include "reid_gram.hip.inc"
 #include "reid_halo.hip.inc"
 #include "reid_kwave.hip.inc"
-#include "gemm_glds.hip.inc"
-#include "reid_wdirect.hip.inc"
 #include "reid_pipe.hip.inc"
 #include "reid_f32.hip.inc"
 #include "reid_x3.hip.inc"
@@ -57,7 +55,6 @@ struct BuscaOptions {
     int dt_tiled = 0;         // BUSCA_DT_TILED: force the layer-wise Decision-Transformer path
     int dtl_rt = 0;           // BUSCA_DTL_RT: 2 / 4 = 64- / 128-row tiles of the layer-wise GEMMs (0 = automatic)
     int dtl_rt_mask = -1;     // BUSCA_DTL_RT_MASK: bit EPI = 64-row tiles for that GEMM kind (-1 = off)
-    int dtl_glds = 0;         // BUSCA_DTL_GLDS: QKV / FFN1 through the direct-to-LDS GEMM
     int dtl_ffn = 2;          // BUSCA_DTL_FFN: 2 = the layer-wise path runs out-proj + norm1 + feed-forward + norm2 as ONE kernel, 1 = the feed-forward block only,
                               // 0 = one kernel per GEMM (H and x1 through HBM)
     int dtl_attn = 1;         // BUSCA_DTL_ATTN: 1 = QKV projection + attention of a (track, head) in one kernel where it is built (0: QKV GEMM + attention kernel)
@@ -66,7 +63,7 @@ struct BuscaOptions {
     static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
     void from_env() {
         dt_ntrk = env_int("BUSCA_DT_NTRK", 0); dt_tiled = getenv("BUSCA_DT_TILED") != nullptr ? 1 : 0;
-        dtl_rt = env_int("BUSCA_DTL_RT", 0); dtl_rt_mask = env_int("BUSCA_DTL_RT_MASK", -1); dtl_glds = env_int("BUSCA_DTL_GLDS", 0);
+        dtl_rt = env_int("BUSCA_DTL_RT", 0); dtl_rt_mask = env_int("BUSCA_DTL_RT_MASK", -1);
         dt_prof = getenv("BUSCA_DT_PROF") != nullptr ? 1 : 0;
         dtl_ffn = env_int("BUSCA_DTL_FFN", 2); dtl_attn = env_int("BUSCA_DTL_ATTN", 1);
     }
@@ -148,18 +145,18 @@ extern "C" const char* busca_build_info(void) { return "libbusca_hip gfx950 flag
 // loaded; through busca_set_option they change between two forwards of a loaded extractor (A/B runs, the tests that compare schedules).
 static int* reid_option_field(ReidState& R, const std::string& n) {
     struct { const char* name; int* p; } tab[] = {
-        {"reid_gram", &R.gram_mode}, {"reid_splitk_blocks", &R.splitk_blocks}, {"reid_halo_min", &R.halo_min_blocks}, {"reid_halo_half", &R.halo_half_blocks},
+        {"reid_gram", &R.gram_mode}, {"reid_halo_min", &R.halo_min_blocks}, {"reid_halo_half", &R.halo_half_blocks},
         {"reid_halo_wpx", &R.halo_wpx}, {"reid_halo_wpx_min", &R.halo_wpx_min}, {"reid_gram_min", &R.gram_min_pixels}, {"reid_direct_rows", &R.direct_rows},
         {"reid_fuse_ds_layers", &R.fuse_ds_layers}, {"reid_fuse_c1_layers", &R.fuse_c1_layers}, {"reid_kwave_blocks", &R.kwave_blocks},
-        {"reid_kwave_halo", &R.kwave_halo_blocks}, {"reid_kwave_nw", &R.kwave_nw}, {"reid_kwave_pt", &R.kwave_pt}, {"reid_glds_min", &R.glds_min_tiles},
-        {"reid_glds_bm", &R.glds_bm}, {"reid_wd_min", &R.wd_min_tiles}, {"reid_pipe_min", &R.pipe_min_tiles}, {"reid_pipe_half", &R.pipe_half_blocks},
+        {"reid_kwave_halo", &R.kwave_halo_blocks}, {"reid_kwave_nw", &R.kwave_nw}, {"reid_kwave_pt", &R.kwave_pt}, 
+        {"reid_pipe_min", &R.pipe_min_tiles}, {"reid_pipe_half", &R.pipe_half_blocks},
         {"reid_x3_merge_layers", &R.x3_merge_layers}, {"reid_x3_half", &R.x3_half_blocks}, {"reid_x3_gram_min", &R.x3_gram_min}, {"reid_x3_merge_in_min", &R.x3_merge_in_min}, {"reid_x3_fuse_c1_min", &R.x3_fuse_c1_min}, {"reid_x3_narrow3", &R.x3_narrow3}, {"reid_x3_row3", &R.x3_row3}, {"reid_x3_ptail", &R.x3_ptail_min}};
     for (auto& e : tab) if (n == e.name) return e.p;
     return nullptr;
 }
 static bool* reid_option_flag(ReidState& R, const std::string& n) {
     struct { const char* name; bool* p; } tab[] = {{"reid_halo", &R.halo}, {"reid_fuse_c1", &R.fuse_c1}, {"reid_fuse_c1_small", &R.fuse_c1_small},
-                                                   {"reid_stats2", &R.two_launch_stats}, {"reid_pipe_all", &R.pipe_all}, {"reid_wd_all", &R.wd_all}, {"reid_x3_gram", &R.x3_gram}, {"reid_x3_merge_in", &R.x3_merge_in}, {"reid_x3_fuse_c1", &R.x3_fuse_c1}, {"reid_x3_stem_halo", &R.x3_stem_halo}, {"reid_x3_stem_u8", &R.x3_stem_u8}, {"reid_x3_stem_pool", &R.x3_stem_pool}};
+                                                   {"reid_stats2", &R.two_launch_stats}, {"reid_pipe_all", &R.pipe_all}, {"reid_x3_gram", &R.x3_gram}, {"reid_x3_merge_in", &R.x3_merge_in}, {"reid_x3_fuse_c1", &R.x3_fuse_c1}, {"reid_x3_stem_halo", &R.x3_stem_halo}, {"reid_x3_stem_u8", &R.x3_stem_u8}, {"reid_x3_stem_pool", &R.x3_stem_pool}};
     for (auto& e : tab) if (n == e.name) return e.p;
     return nullptr;
 }
@@ -178,7 +175,6 @@ extern "C" int busca_set_option(busca_ctx* c, const char* name, int32_t value) {
     else if (n == "dt_tiled") o.dt_tiled = value;
     else if (n == "dtl_rt") o.dtl_rt = value;
     else if (n == "dtl_rt_mask") o.dtl_rt_mask = value;
-    else if (n == "dtl_glds") o.dtl_glds = value;
     else if (n == "dtl_ffn") o.dtl_ffn = value;
     else if (n == "dtl_attn") o.dtl_attn = value;
     else return fail(c, BUSCA_EINVAL, "busca_set_option: unknown option '%s'", name);
@@ -197,7 +193,6 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
     else if (n == "dt_tiled") *value = o.dt_tiled;
     else if (n == "dtl_rt") *value = o.dtl_rt;
     else if (n == "dtl_rt_mask") *value = o.dtl_rt_mask;
-    else if (n == "dtl_glds") *value = o.dtl_glds;
     else if (n == "dtl_ffn") *value = o.dtl_ffn;
     else if (n == "dtl_attn") *value = o.dtl_attn;
     else if (n == "last_dt_grid") *value = o.last_dt_grid;
@@ -475,35 +470,6 @@ static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblock
     return dtl_gemm_rt<PREC, D, EPI, 4>(c, s, a, ncolblocks);
 }
 
-// QKV / FFN1 (no row-wise epilogue) in f16 through the direct-to-LDS GEMM of gemm_glds.hip.inc (256-column tiles, staggered wave
-// groups) with BUSCA_DTL_GLDS=1.  Off by default: 512 x 64 x d512 QKV 211 -> 221 us, FFN1 168 -> 161 us - the LDS-DMA path
-// delivers ~20 B/clk/CU, a third of what the VGPR path of dtl_gemm_kernel moves.
-template <int EPI>
-static bool dtl_gemm_glds(busca_ctx* c, hipStream_t s, const DTLArgs& a, int N, int qcols, int* rc_out) {
-    const int on = c->opt.dtl_glds;      // measured equal to dtl_gemm_kernel (see gemm_glds.hip.inc): opt-in
-    *rc_out = BUSCA_OK;
-    if (!on || N % 256 != 0 || a.K % 32 != 0 || a.K < 96) return false;
-    const long t256 = (long)((a.M + 255) / 256) * (N / 256);
-    if (t256 < 128) return false;
-    GemmGldsArgs g{};
-    g.X = (const _Float16*)a.A; g.ldx = a.lda; g.W = (const _Float16*)a.W; g.ldw = a.K; g.M = a.M; g.N = N; g.K = a.K;
-    g.out = (_Float16*)a.out16; g.ldo = a.ldo; g.bias = a.bias; g.qscale = a.qscale; g.qcols = qcols; g.act = a.act;
-    const bool big = t256 >= 512;
-    const int bm = big ? 256 : 128;
-    g.gridM = (a.M + bm - 1) / bm; g.gridN = N / 256;
-    const unsigned nb = (unsigned)(((g.gridM + 7) / 8) * 8 * g.gridN);
-    const size_t lds = (size_t)4 * (bm * 64 + 256 * 64);
-    TimedLaunch tl(c, s);
-    if (big) {
-        *rc_out = ensure_lds(c, (const void*)gemm_glds_kernel<8, EPI>, lds); if (*rc_out) return true;
-        hipLaunchKernelGGL((gemm_glds_kernel<8, EPI>), dim3(nb), dim3(512), lds, s, g);
-    } else {
-        *rc_out = ensure_lds(c, (const void*)gemm_glds_kernel<4, EPI>, lds); if (*rc_out) return true;
-        hipLaunchKernelGGL((gemm_glds_kernel<4, EPI>), dim3(nb), dim3(512), lds, s, g);
-    }
-    return true;
-}
-
 template <int PREC, int HD, int MT>
 static int dtl_attention(busca_ctx* c, hipStream_t s, const void* qkv, void* O, int B, int T, int D, int NH, float* att) {
     constexpr int ES = Prec<PREC>::ES, TPK = Prec<PREC>::CHUNK * Prec<PREC>::nchunks(MT);
@@ -628,8 +594,7 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
         if (!fused_attn) {
             a.A = Xop; a.lda = D; a.W = S.tw.w_in[l]; a.K = D; a.bias = W.b_in; a.out16 = QKV; a.ldo = 3 * D;
             {
-                int rc = BUSCA_OK;
-                if (!(PREC == 1 && dtl_gemm_glds<GEMM_EPI_BIAS_QSCALE>(c, s, a, 3 * D, D, &rc))) rc = dtl_gemm<PREC, D, DTL_EPI_QKV>(c, s, a, 3);
+                int rc = dtl_gemm<PREC, D, DTL_EPI_QKV>(c, s, a, 3);
                 if (rc) return rc;
             }
             { int rc = dtl_attention_hd<PREC>(c, s, MT, QKV, O, B, T, D, NH, att); if (rc) return rc; }
@@ -661,8 +626,7 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
         }
         a.A = Xop; a.lda = D; a.W = S.tw.w1[l]; a.K = D; a.bias = W.b1; a.out16 = H; a.ldo = FF;
         {
-            int rc = BUSCA_OK;
-            if (!(PREC == 1 && dtl_gemm_glds<GEMM_EPI_BIAS_ACT>(c, s, a, FF, 0, &rc))) rc = dtl_gemm<PREC, D, DTL_EPI_FFN1>(c, s, a, FF / D);
+            int rc = dtl_gemm<PREC, D, DTL_EPI_FFN1>(c, s, a, FF / D);
             if (rc) return rc;
         }
         a.A = H; a.lda = FF; a.W = S.tw.w2[l]; a.K = FF; a.bias = W.b2; a.gamma = W.g2; a.beta = W.be2;

@@ -52,15 +52,15 @@ int busca_version(void);
 /* The compiler flags this library was built with (busca_amd/build.py passes them in; bench.py records the string). */
 const char* busca_build_info(void);
 /* Developer options of one context (kernel-flavour selection for A/B runs and the tests that compare flavours).  Defaults are read
- * from the environment ONCE, at busca_ctx_create (BUSCA_DT_NTRK, BUSCA_DT_TILED, BUSCA_DTL_RT, BUSCA_DTL_RT_MASK, BUSCA_DTL_GLDS);
+ * from the environment ONCE, at busca_ctx_create (BUSCA_DT_NTRK, BUSCA_DT_TILED, BUSCA_DTL_RT, BUSCA_DTL_RT_MASK);
  * no forward reads the environment.  Names: "dt_ntrk" (0 auto / 1 / 2 tracks per workgroup of the f16 fused kernel), "dt_tiled"
- * (1 = force the layer-wise path), "dtl_rt" (0 auto / 2 / 4), "dtl_rt_mask" (-1 off), "dtl_glds" (0 / 1), "dtl_ffn" (2 = out-proj + norm1 + feed-forward + norm2 of the layer-wise path as one kernel, 1 = feed-forward block only, 0 = one kernel per GEMM; BUSCA_DTL_FFN), "dtl_attn" (1 = QKV projection + attention of a (track, head) as one kernel where built; BUSCA_DTL_ATTN); busca_get_option also
+ * (1 = force the layer-wise path), "dtl_rt" (0 auto / 2 / 4), "dtl_rt_mask" (-1 off), "dtl_ffn" (2 = out-proj + norm1 + feed-forward + norm2 of the layer-wise path as one kernel, 1 = feed-forward block only, 0 = one kernel per GEMM; BUSCA_DTL_FFN), "dtl_attn" (1 = QKV projection + attention of a (track, head) as one kernel where built; BUSCA_DTL_ATTN); busca_get_option also
  * answers "last_dt_grid" / "last_dt_ntrk" (workgroups and tracks per workgroup of the last fused launch).  Unknown name: BUSCA_EINVAL.
  * ReID schedule knobs of a LOADED extractor (they start from the BUSCA_REID_* environment at busca_reid_load_weights and can be changed between
- * forwards): "reid_gram", "reid_halo", "reid_fuse_c1", "reid_fuse_c1_layers", "reid_fuse_c1_small", "reid_fuse_ds_layers", "reid_splitk_blocks",
+ * forwards): "reid_gram", "reid_halo", "reid_fuse_c1", "reid_fuse_c1_layers", "reid_fuse_c1_small", "reid_fuse_ds_layers",
  * "reid_halo_min", "reid_halo_half", "reid_halo_wpx", "reid_halo_wpx_min", "reid_gram_min", "reid_direct_rows", "reid_stats2", "reid_kwave_blocks",
- * "reid_kwave_halo", "reid_kwave_nw", "reid_kwave_pt", "reid_glds_min", "reid_glds_bm", "reid_wd_min", "reid_wd_all", "reid_pipe_min", "reid_pipe_half",
- * "reid_pipe_all", "reid_x3_merge_layers", "reid_x3_half", "reid_x3_gram", "reid_x3_gram_min", "reid_x3_merge_in", "reid_x3_merge_in_min", "reid_x3_fuse_c1", "reid_x3_fuse_c1_min", "reid_x3_narrow3", "reid_x3_row3", "reid_x3_stem_halo", "reid_x3_stem_u8", "reid_x3_stem_pool" (meanings: DESIGN.md section 5).  Before weights are loaded: BUSCA_ENOWEIGHTS. */
+ * "reid_kwave_halo", "reid_kwave_nw", "reid_kwave_pt", "reid_pipe_min", "reid_pipe_half",
+ * "reid_pipe_all", "reid_x3_merge_layers", "reid_x3_half", "reid_x3_gram", "reid_x3_gram_min", "reid_x3_merge_in", "reid_x3_merge_in_min", "reid_x3_fuse_c1", "reid_x3_fuse_c1_min", "reid_x3_narrow3", "reid_x3_row3", "reid_x3_ptail", "reid_x3_stem_halo", "reid_x3_stem_u8", "reid_x3_stem_pool" (meanings: DESIGN.md section 5).  Before weights are loaded: BUSCA_ENOWEIGHTS. */
 int busca_set_option(busca_ctx* ctx, const char* name, int32_t value);
 int busca_get_option(busca_ctx* ctx, const char* name, int32_t* value);
 

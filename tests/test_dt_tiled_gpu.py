@@ -86,28 +86,6 @@ def test_tiled_large_shapes_vs_oracle(ctx, shape, prec):
     assert (out["argmax"][clear] == ref["argmax"].numpy()[clear]).all()
 
 
-def test_tiled_glds_gemm_flavour(ctx, force_tiled):
-    """BUSCA_DTL_GLDS=1 routes the QKV / FFN1 products of the layer-wise f16 path through the direct-to-LDS GEMM
-    (gemm_glds.hip.inc, 128- and 256-row tiles): same tolerances against the oracle, and close to the default kernel."""
-    from busca_amd.dt import DecisionTransformerHIP
-    from oracle import dt as odt
-    for (B, L, P, d) in [(128, 11, 32, 512), (300, 11, 32, 256)]:
-        seed = 400 + P + d
-        sd = synth.dt_state_dict(seed, d=d, ff=2 * d)
-        inp = synth.dt_inputs(seed, B, L, P, sentinel_every=8)
-        m = DecisionTransformerHIP(ctx, sd, precision="f16")
-        ctx.set_option("dtl_glds", 0)
-        base = {k: v.cpu().numpy() for k, v in m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"]).items()}
-        ctx.set_option("dtl_glds", 1)
-        out = {k: v.cpu().numpy() for k, v in m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"]).items()}
-        ref = odt.dt_forward(sd, odt.DTConfig(d=d, ff=2 * d), **inp, return_all=True)
-        assert np.abs(out["logits"] - ref["logits"].numpy()).max() <= TOL["logit"]
-        assert np.abs(out["probs"] - ref["probs"].numpy()).max() <= TOL["prob"]
-        ctx.set_option("dtl_glds", 0)
-        assert np.abs(out["probs"] - base["probs"]).max() <= TOL["prob"]
-        assert ctx.get_option("dtl_glds") == 0        # (both GEMM kernels walk K in the same order: their outputs are bit-identical)
-
-
 def test_unsupported_shape_is_refused_loudly(ctx):
     """More than 144 tokens per track is beyond every path: a BuscaError, never a silent fallback."""
     from busca_amd import _lib

@@ -140,9 +140,9 @@ def test_reid_default_large_batch_schedule_vs_reference(ctx, golden_dir, monkeyp
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     from make_golden import smooth_crops
     from busca_amd.reid import ReIDEncoderHIP
-    for k in ("BUSCA_REID_GRAM", "BUSCA_REID_HALO", "BUSCA_REID_FUSE_C1", "BUSCA_REID_SPLITK_BLOCKS", "BUSCA_REID_DIRECT_ROWS",
+    for k in ("BUSCA_REID_GRAM", "BUSCA_REID_HALO", "BUSCA_REID_FUSE_C1", "BUSCA_REID_DIRECT_ROWS",
               "BUSCA_REID_KWAVE_BLOCKS", "BUSCA_REID_KWAVE_HALO", "BUSCA_REID_KWAVE_NW", "BUSCA_REID_KWAVE_PT",
-              "BUSCA_REID_GLDS_MIN", "BUSCA_REID_GLDS_BM", "BUSCA_REID_WD_MIN"):
+              ):
         monkeypatch.delenv(k, raising=False)
     ref = np.load(os.path.join(golden_dir, "reid_big.npz"))["feats_n%d_seed%d" % (n, seed)]
     sd = synth.reid_state_dict(3)
@@ -319,34 +319,6 @@ def test_reid_kwave_conv_path(ctx, monkeypatch, n, nw, pt):
     ReIDEncoderHIP(ctx, sd)
 
 
-@pytest.mark.parametrize("n,bm", [(7, 128), (24, 256), (40, 128)])
-def test_reid_glds_gemm_path(ctx, monkeypatch, n, bm):
-    """Transform-free 1x1 convs (conv1 of the layer-3 / layer-4 bottlenecks) as plain GEMMs with direct-to-LDS operand loads
-    (gemm_glds.hip.inc; automatic from 192 tiles = 256 crops).  Forced on at small batches (ragged last row tile included):
-    same stored roundings as the tiled kernel, different f32 summation order."""
-    from busca_amd.reid import ReIDEncoderHIP
-    from oracle import reid as oreid
-    sd = synth.reid_state_dict(3)
-    crops = _crops(1700 + n, n)
-    monkeypatch.setenv("BUSCA_REID_KWAVE_BLOCKS", "0")
-    monkeypatch.setenv("BUSCA_REID_GLDS_MIN", "0")
-    tiled = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
-    monkeypatch.setenv("BUSCA_REID_GLDS_MIN", "1")
-    monkeypatch.setenv("BUSCA_REID_GLDS_BM", str(bm))
-    m = ReIDEncoderHIP(ctx, sd)
-    got = m.forward(crops).cpu().numpy()
-    assert np.array_equal(got, m.forward(crops).cpu().numpy())
-    assert np.abs(got - tiled).max() <= 5e-3, np.abs(got - tiled).max()
-    assert (got * tiled).sum(1).min() >= 0.9998
-    if n <= 8:
-        ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
-        assert (got * ref).sum(1).min() >= COS_MIN
-        assert np.abs(got - ref).max() <= FEAT_ATOL
-    for k in ("BUSCA_REID_KWAVE_BLOCKS", "BUSCA_REID_GLDS_MIN", "BUSCA_REID_GLDS_BM"):
-        monkeypatch.delenv(k, raising=False)
-    ReIDEncoderHIP(ctx, sd)
-
-
 @pytest.mark.parametrize("n", [7, 24])
 def test_reid_pipelined_conv_path(ctx, monkeypatch, n):
     """conv_pipe_kernel (reid_pipe.hip.inc: weights direct into a three-deep register ring, two LDS activation tiles, one barrier per K
@@ -357,7 +329,7 @@ def test_reid_pipelined_conv_path(ctx, monkeypatch, n):
     from oracle import reid as oreid
     sd = synth.reid_state_dict(3)
     crops = _crops(1900 + n, n)
-    knobs = {"BUSCA_REID_KWAVE_BLOCKS": "0", "BUSCA_REID_HALO_MIN": "100000", "BUSCA_REID_WD_MIN": "0", "BUSCA_REID_SPLITK_BLOCKS": "0"}
+    knobs = {"BUSCA_REID_KWAVE_BLOCKS": "0", "BUSCA_REID_HALO_MIN": "100000"}
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     monkeypatch.setenv("BUSCA_REID_PIPE_MIN", "0")
@@ -384,34 +356,6 @@ def test_reid_pipelined_conv_path(ctx, monkeypatch, n):
     ReIDEncoderHIP(ctx, sd)
 
 
-@pytest.mark.parametrize("n", [7, 24])
-def test_reid_weights_direct_1x1_path(ctx, monkeypatch, n):
-    """Large launches run the 1x1 convs with 256-multiple output channels (conv1 / conv3 statistics pass / fused block tail of
-    layers 3-4, conv3 of layer 2) through conv1x1_wd_kernel (weights streamed into MFMA fragments, reid_wdirect.hip.inc;
-    automatic from 256 tiles).  Forced on at small batches with ragged last tiles: same stored roundings as the tiled kernel."""
-    from busca_amd.reid import ReIDEncoderHIP
-    from oracle import reid as oreid
-    sd = synth.reid_state_dict(3)
-    crops = _crops(1900 + n, n)
-    monkeypatch.setenv("BUSCA_REID_KWAVE_BLOCKS", "0")
-    monkeypatch.setenv("BUSCA_REID_WD_MIN", "0")
-    tiled = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()
-    monkeypatch.setenv("BUSCA_REID_WD_MIN", "1")
-    monkeypatch.setenv("BUSCA_REID_WD_ALL", "1")               # all three epilogue modes, not only the shapes the default picks
-    m = ReIDEncoderHIP(ctx, sd)
-    got = m.forward(crops).cpu().numpy()
-    assert np.array_equal(got, m.forward(crops).cpu().numpy())
-    assert np.abs(got - tiled).max() <= 5e-3, np.abs(got - tiled).max()
-    assert (got * tiled).sum(1).min() >= 0.9998
-    if n <= 8:
-        ref = oreid.reid_forward(sd, oreid.crops_to_reid_input(crops)).numpy()
-        assert (got * ref).sum(1).min() >= COS_MIN
-        assert np.abs(got - ref).max() <= FEAT_ATOL
-    for k in ("BUSCA_REID_KWAVE_BLOCKS", "BUSCA_REID_WD_MIN", "BUSCA_REID_WD_ALL"):
-        monkeypatch.delenv(k, raising=False)
-    ReIDEncoderHIP(ctx, sd)
-
-
 @pytest.mark.parametrize("n", [1, 13, 33, 65, 129, 193])
 def test_reid_default_schedule_vs_plain_tiled_schedule(ctx, monkeypatch, n):
     """Batch sizes on both sides of the launch-time switch-overs (K-split kernel below 288 tiles / 600 MB, half-image halo tiles
@@ -420,7 +364,7 @@ def test_reid_default_schedule_vs_plain_tiled_schedule(ctx, monkeypatch, n):
     from busca_amd.reid import ReIDEncoderHIP
     sd = synth.reid_state_dict(3)
     crops = _crops(2100 + n, n)
-    plain_env = {"BUSCA_REID_KWAVE_BLOCKS": "0", "BUSCA_REID_WD_MIN": "0", "BUSCA_REID_HALO_HALF": "0", "BUSCA_REID_GRAM": "0", "BUSCA_REID_FUSE_C1": "0"}
+    plain_env = {"BUSCA_REID_KWAVE_BLOCKS": "0", "BUSCA_REID_HALO_HALF": "0", "BUSCA_REID_GRAM": "0", "BUSCA_REID_FUSE_C1": "0"}
     for k in plain_env:
         monkeypatch.delenv(k, raising=False)
     a = ReIDEncoderHIP(ctx, sd).forward(crops).cpu().numpy()

@@ -8,7 +8,7 @@ import numpy as np, torch
 from busca_amd import _lib, synth
 from busca_amd.reid import ReIDEncoderHIP
 
-PLAIN = {"BUSCA_REID_KWAVE_BLOCKS": "0", "BUSCA_REID_WD_MIN": "0", "BUSCA_REID_HALO_HALF": "0", "BUSCA_REID_GRAM": "0", "BUSCA_REID_FUSE_C1": "0"}
+PLAIN = {"BUSCA_REID_KWAVE_BLOCKS": "0", "BUSCA_REID_HALO_HALF": "0", "BUSCA_REID_GRAM": "0", "BUSCA_REID_FUSE_C1": "0"}
 sizes = [int(a) for a in sys.argv[1:]] or [1, 2, 9, 12, 13, 24, 25, 31, 33, 47, 49, 64, 65, 86, 127, 129, 171, 191, 193, 257, 342, 400]
 ctx = _lib.Context(0)
 sd = synth.reid_state_dict(3)

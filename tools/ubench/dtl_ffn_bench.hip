@@ -1,5 +1,6 @@
 // Stand-alone check + timing of dtl_ffn_kernel (busca_amd/csrc/dt_tiled.hip.inc) against a float64 host evaluation.
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form tools/ubench/dtl_ffn_bench.hip -o tools/ubench/dtl_ffn_bench
+#define DTL_FFN_UBENCH
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <algorithm>
