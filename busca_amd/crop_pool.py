@@ -17,7 +17,6 @@ HBM use is therefore flat once the budget is reached, whatever the sequence leng
 """
 import os
 import weakref
-from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -26,13 +25,26 @@ CROP_H, CROP_W = 384, 128
 CROP_BYTES = CROP_H * CROP_W * 3
 
 
-class Slot:
-    """One live crop of the pool.  `ptr` is its device address (0 once spilled); `host` its host bytes (None until needed)."""
+class Slot(np.lib.mixins.NDArrayOperatorsMixin):
+    """One live crop of the pool AND the object a tracker stores (`crops[i]` of the lazy / device-only get_image_crops modes; alias
+    tracking.DeviceCrop): round 5 merged the two - one Python object per crop instead of a Slot, a DeviceCrop wrapper and a (frame, row) tuple.
+    `ptr` is its device address (0 once spilled); `host` its host bytes (None until needed).  To duck-typing callers it is a uint8
+    [384,128,3] array: any host read (`np.array(crop)`, arithmetic, `.astype`, indexing, pickling) returns the real pixels - from the
+    frame's asynchronous host copy (lazy mode) or by copying the slot back on demand (device-only mode)."""
     __slots__ = ("pool", "slab", "index", "ptr", "host", "host_src", "__weakref__")
+    shape, dtype, ndim, size = (CROP_H, CROP_W, 3), np.dtype(np.uint8), 3, CROP_BYTES
 
-    def __init__(self, pool, slab, index, ptr):
+    def __init__(self, pool, slab, index, ptr, host_src=None):
         self.pool, self.slab, self.index, self.ptr, self.host = pool, slab, index, ptr, None
-        self.host_src = None                # (frame host copy in flight, row): tracking.FrameHostCopy of get_image_crops' lazy mode
+        self.host_src = host_src            # (frame host copy in flight, row): tracking.FrameHostCopy of get_image_crops' lazy mode
+
+    @property
+    def slot(self):
+        return self
+
+    @property
+    def dev(self):
+        return self.tensor()
 
     def tensor(self):
         """cuda u8 [384,128,3] view of the slot, or None after a spill."""
@@ -53,6 +65,30 @@ class Slot:
             self.host = t.cpu().numpy() if t.is_cuda else t.numpy().copy()     # (.cpu() of a host tensor would alias the slot)
         return self.host
 
+    # ---- the array face ------------------------------------------------------------------------------------------------
+    def __array__(self, dtype=None, copy=None):
+        a = self.host_bytes()
+        return a if dtype is None else a.astype(dtype)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        inputs = tuple(np.asarray(x) if isinstance(x, Slot) else x for x in inputs)
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def astype(self, dtype, **kw):
+        return np.asarray(self).astype(dtype, **kw)
+
+    def copy(self):
+        return np.array(self.host_bytes())
+
+    def __getitem__(self, key):
+        return np.asarray(self)[key]
+
+    def __len__(self):
+        return CROP_H
+
+    def __reduce__(self):
+        return np.asarray(self).__reduce__()
+
     def __del__(self):
         try:
             self.pool._release(self)
@@ -70,7 +106,7 @@ class CropPool:
         self.slabs = []
         self.slab_ptrs = []                 # data_ptr() of every slab (asked once, not per slot)
         self.free = []                      # (slab, index)
-        self.live = OrderedDict()           # id -> weakref(Slot), allocation order = eviction order
+        self.live = {}                      # id -> weakref(Slot); dicts keep insertion order: allocation order = eviction order
         self.spilled = 0                    # crops moved to the host because the budget was reached
         self.peak_live = 0
 
@@ -100,7 +136,7 @@ class CropPool:
         if k > len(self.live):
             raise RuntimeError("crop pool budget (%d crops) is smaller than one request" % (self.max_slabs * self.slab_crops))
         for _ in range(k):
-            _, ref = self.live.popitem(last=False)
+            ref = self.live.pop(next(iter(self.live)))
             slot = ref()
             if slot is None or not slot.ptr:
                 continue
@@ -109,8 +145,9 @@ class CropPool:
             slot.ptr = 0
             self.spilled += 1
 
-    def alloc(self, n):
-        """n fresh slots (list of Slot).  Their contents are undefined until a kernel writes them."""
+    def alloc(self, n, host_frame=None):
+        """n fresh slots (list of Slot).  Their contents are undefined until a kernel writes them.  `host_frame`: the FrameHostCopy whose row k will
+        hold slot k's host bytes (lazy mode)."""
         while len(self.free) < n:
             if len(self.slabs) < self.max_slabs:
                 self._grow()
@@ -118,9 +155,9 @@ class CropPool:
                 self._spill_oldest(n - len(self.free))
         out = []
         free, live, ptrs, ref = self.free, self.live, self.slab_ptrs, weakref.ref
-        for _ in range(n):
+        for k in range(n):
             s, i = free.pop()
-            slot = Slot(self, s, i, ptrs[s] + i * CROP_BYTES)
+            slot = Slot(self, s, i, ptrs[s] + i * CROP_BYTES, None if host_frame is None else (host_frame, k))
             live[id(slot)] = ref(slot)
             out.append(slot)
         self.peak_live = max(self.peak_live, len(self.live))

@@ -59,13 +59,14 @@ struct BuscaOptions {
                               // 0 = one kernel per GEMM (H and x1 through HBM)
     int dtl_attn = 1;         // BUSCA_DTL_ATTN: 1 = QKV projection + attention of a (track, head) in one kernel where it is built (0: QKV GEMM + attention kernel)
     int dt_prof = 0;          // BUSCA_DT_PROF: phase stamps of the fused kernel (debug)
+    int crop_band = 1;        // BUSCA_CROP_BAND: 1 = crops through the LDS-staged band kernel (crop_band_kernel), 0 = one thread per output pixel (A/B, tests)
     int last_dt_grid = 0, last_dt_ntrk = 0;     // read-only: workgroups / tracks per workgroup of the last fused launch
     static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
     void from_env() {
         dt_ntrk = env_int("BUSCA_DT_NTRK", 0); dt_tiled = getenv("BUSCA_DT_TILED") != nullptr ? 1 : 0;
         dtl_rt = env_int("BUSCA_DTL_RT", 0); dtl_rt_mask = env_int("BUSCA_DTL_RT_MASK", -1);
         dt_prof = getenv("BUSCA_DT_PROF") != nullptr ? 1 : 0;
-        dtl_ffn = env_int("BUSCA_DTL_FFN", 2); dtl_attn = env_int("BUSCA_DTL_ATTN", 1);
+        dtl_ffn = env_int("BUSCA_DTL_FFN", 2); dtl_attn = env_int("BUSCA_DTL_ATTN", 1); crop_band = env_int("BUSCA_CROP_BAND", 1);
     }
 };
 
@@ -177,6 +178,7 @@ extern "C" int busca_set_option(busca_ctx* c, const char* name, int32_t value) {
     else if (n == "dtl_rt_mask") o.dtl_rt_mask = value;
     else if (n == "dtl_ffn") o.dtl_ffn = value;
     else if (n == "dtl_attn") o.dtl_attn = value;
+    else if (n == "crop_band") o.crop_band = value;
     else return fail(c, BUSCA_EINVAL, "busca_set_option: unknown option '%s'", name);
     return BUSCA_OK;
 }
@@ -195,6 +197,7 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
     else if (n == "dtl_rt_mask") *value = o.dtl_rt_mask;
     else if (n == "dtl_ffn") *value = o.dtl_ffn;
     else if (n == "dtl_attn") *value = o.dtl_attn;
+    else if (n == "crop_band") *value = o.crop_band;
     else if (n == "last_dt_grid") *value = o.last_dt_grid;
     else if (n == "last_dt_ntrk") *value = o.last_dt_ntrk;
     else return fail(c, BUSCA_EINVAL, "busca_get_option: unknown option '%s'", name);

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib, geometry
+from .crop_pool import Slot
 
 _F32_MIN = np.finfo("float32").min
 
@@ -151,67 +152,29 @@ class DeviceBackedCrops(np.ndarray):
 
 
 class FrameHostCopy:
-    """The host bytes of one get_image_crops call, on their way: the crops were written into pool slots on the GPU; one
-    asynchronous device->host copy of all of them into PINNED memory runs on a side stream, and the first HOST read of any
-    of the crops waits for its event (usually long past).  A tracker that never looks at pixels never waits."""
-    __slots__ = ("host", "event", "_np", "expired")
+    """The host bytes of one get_image_crops call, ON DEMAND (round 5): the crops live in pool slots; nothing is copied to the host until somebody
+    reads a pixel.  The first host read of ANY crop of the call fetches the WHOLE batch in one go - one index-gather launch over the call's slots
+    (busca_gather_crops) and one device->host copy - so a tracker that looks at every crop pays one transfer per call, and one that never looks
+    (the five adapters only store the crops and hand them back to associate_embeddings) pays nothing: no pinned buffer, no copy, no side stream
+    (rounds 3-4 enqueued a 17 MB pinned copy per call whether or not anyone read it: 0.12 ms of host time per call).
+    A slot that was released and reused before the read shows another crop's bytes in its row - a row nobody can ask for any more."""
+    __slots__ = ("ctx", "ptrs", "event", "_np", "expired")
 
-    def __init__(self, host, event):
-        self.host, self.event, self._np, self.expired = host, event, None, False
+    def __init__(self, ctx=None, ptrs=None, event=None):
+        self.ctx, self.ptrs, self.event, self._np, self.expired = ctx, ptrs, event, None, False
 
     def rows(self):
-        """uint8 [n,384,128,3] host view of the batch, or None once the copy has been retired (the crops then read their pool slot)."""
-        if self.expired:
-            return None
+        """uint8 [n,384,128,3] host view of the batch (fetched on the first call)."""
         if self._np is None:
-            self.event.synchronize()
-            self._np = self.host.numpy()
+            dev = torch.device("cuda", self.ctx.device)
+            if self.event is not None:
+                torch.cuda.current_stream(dev).wait_event(self.event)      # the crop kernel may have run on another stream
+            self._np = geometry.gather_crops(self.ctx, self.ptrs).cpu().numpy()
             self.event = None
         return self._np
 
-    def retire(self):
-        """Give the pinned buffer back (views already handed out keep their memory alive through numpy's base reference)."""
-        if self.event is not None:
-            self.event.synchronize()
-        self.host, self.event, self._np, self.expired = None, None, None, True
 
-
-class DeviceCrop(np.lib.mixins.NDArrayOperatorsMixin):
-    """One crop of `get_image_crops(..., normalize=False)` in its lazy (default) and device-only modes: lives in its pool slot;
-    any host read (`np.array(crop)`, arithmetic, `.astype`, pickling) returns the real pixels - from the frame's asynchronous
-    host copy (lazy mode) or by copying the slot back on demand (device-only mode).  There are no placeholder bytes that
-    could leak into a BatchNorm batch."""
-    shape, dtype, ndim, size = (384, 128, 3), np.dtype(np.uint8), 3, 384 * 128 * 3
-
-    def __init__(self, slot):
-        self.slot = slot
-
-    @property
-    def dev(self):
-        return self.slot.tensor()
-
-    def __array__(self, dtype=None, copy=None):
-        a = self.slot.host_bytes()
-        return a if dtype is None else a.astype(dtype)
-
-    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
-        inputs = tuple(np.asarray(x) if isinstance(x, DeviceCrop) else x for x in inputs)
-        return getattr(ufunc, method)(*inputs, **kwargs)
-
-    def astype(self, dtype, **kw):
-        return np.asarray(self).astype(dtype, **kw)
-
-    def copy(self):
-        return np.array(self.slot.host_bytes())
-
-    def __getitem__(self, key):
-        return np.asarray(self)[key]
-
-    def __len__(self):
-        return 384
-
-    def __reduce__(self):
-        return np.asarray(self).__reduce__()
+DeviceCrop = Slot                       # one object per crop: the pool slot IS what the tracker stores (busca_amd/crop_pool.py)
 
 
 class DeviceCrops:
@@ -219,7 +182,7 @@ class DeviceCrops:
     dtype, ndim = np.dtype(np.uint8), 4
 
     def __init__(self, slots):
-        self._items = [DeviceCrop(s) for s in slots]
+        self._items = list(slots)
 
     @property
     def shape(self):
@@ -252,25 +215,13 @@ def box_extents(bboxes):
     return np.clip(r, -2.0 ** 30, 2.0 ** 30).astype(np.int32)
 
 
-_COPY_STREAMS = {}
-_HOST_COPIES = {}                       # device index -> the FrameHostCopy objects of the last _HOST_COPY_CALLS lazy calls
-_HOST_COPY_CALLS = max(1, int(os.environ.get("BUSCA_AMD_HOST_COPY_CALLS", "8")))
-
-
-def _copy_stream(dev):
-    key = dev.index or 0
-    if key not in _COPY_STREAMS:
-        _COPY_STREAMS[key] = torch.cuda.Stream(dev)
-    return _COPY_STREAMS[key]
-
-
 def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False, host_copy=None, output_size=None):
     """All crops of one frame in one launch: u8 BGR [N,384,128,3] (float32 normalised if `normalize`).
     With normalize=False every crop is written into a slot of the device crop pool and the returned crops remember
     their slot.  `host_copy` says what happens to the HOST bytes of those crops (147 KB each - the bulk of this call when it
     is waited for; busca/network.py:492-507 returns host arrays):
-      "lazy"  (default) the copy of the whole batch into pinned memory is enqueued on a side stream and nobody waits: the
-              returned `DeviceCrops` hand out the pixels on the first host read (which waits for the copy's event);
+      "lazy"  (default) nothing is copied until somebody reads a pixel: the returned `DeviceCrops` fetch the whole batch with one
+              gather + one device->host copy on the first host read of any of its crops;
       "eager" wait for it: a real uint8 ndarray (`DeviceBackedCrops`) - for callers that need ndarray instances;
       "never" (`device_only=True`) no copy at all; a host read copies that one crop back synchronously."""
     rects = box_extents(bboxes)
@@ -291,32 +242,20 @@ def get_image_crops(im, bboxes, normalize=True, ctx=None, device_only=False, hos
     if host_copy not in ("lazy", "eager", "never"):
         raise ValueError("host_copy must be 'lazy', 'eager' or 'never', not %r" % (host_copy,))
     pool = geometry.crop_pool(ctx)
-    slots = pool.alloc(len(rects))
-    ptrs = np.array([s.ptr for s in slots], dtype=np.uint64)
+    frame = FrameHostCopy() if host_copy == "lazy" else None
+    slots = pool.alloc(len(rects), frame)
+    ptrs = np.fromiter((s.ptr for s in slots), dtype=np.uint64, count=len(slots))
     if host_copy == "never":
         geometry.crop_gather(ctx, im, rects, want_u8=False, dst_ptrs=ptrs)
         return DeviceCrops(slots)
-    packed, _ = geometry.crop_gather(ctx, im, rects, want_u8=True, dst_ptrs=ptrs)    # the same launch also writes the batch as one contiguous buffer (the slots need not be adjacent)
     if host_copy == "eager":
+        packed, _ = geometry.crop_gather(ctx, im, rects, want_u8=True, dst_ptrs=ptrs)    # the same launch also writes the batch as one contiguous buffer (the slots need not be adjacent)
         return DeviceBackedCrops(packed.cpu().numpy(), slots)
-    dev = packed.device
-    cur, side = torch.cuda.current_stream(dev), _copy_stream(dev)
-    host = torch.empty(packed.shape, dtype=torch.uint8, pin_memory=True)      # torch's caching host allocator: no hipHostMalloc per frame
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        host.copy_(packed, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(side)
-    packed.record_stream(side)
-    frame = FrameHostCopy(host, ev)
-    for k, sl in enumerate(slots):
-        sl.host_src = (frame, k)
-    # the pinned copies of the last few calls only: a copy every live crop of a frame kept alive made pinned memory grow by 22 MB per frame for as
-    # long as track memories held crops (a fresh hipHostMalloc per call, ~0.3 ms); crops older than that read their pool slot on demand instead
-    ring = _HOST_COPIES.setdefault(dev.index or 0, [])
-    ring.append(frame)
-    while len(ring) > _HOST_COPY_CALLS:
-        ring.pop(0).retire()
+    # lazy: pool slots only; the host bytes are fetched by the first host read (FrameHostCopy)
+    geometry.crop_gather(ctx, im, rects, want_u8=False, dst_ptrs=ptrs)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(torch.device("cuda", ctx.device)))
+    frame.ctx, frame.ptrs, frame.event = ctx, ptrs, ev
     return DeviceCrops(slots)
 
 

@@ -101,8 +101,8 @@ def test_forward_accepts_reference_float_layout(model):
 @pytest.mark.parametrize("host_copy", ["lazy", "eager"])
 def test_device_resident_track_memory(model, host_copy):
     """Crops returned by get_image_crops keep a device twin; association then gathers them on the GPU
-    (no H2D) and gives bit-identical results to the host path.  "lazy" (the default): the host bytes arrive through an asynchronous
-    copy that only a host read waits for; "eager": a real ndarray, as in rounds 2-3."""
+    (no H2D) and gives bit-identical results to the host path.  "lazy" (the default): the host bytes are fetched by the first host
+    read; "eager": a real ndarray, as in rounds 2-3."""
     from busca_amd.tracking import DeviceBackedCrops, DeviceCrops
     import make_golden as mg
     model.pinned_numpy = True
@@ -113,7 +113,7 @@ def test_device_resident_track_memory(model, host_copy):
     model.crop_host_copy = host_copy
     try:
         crops = model.get_image_crops(frame, boxes, normalize=False)
-        again = model.get_image_crops(frame, boxes[:3], normalize=False)          # same frame object: its device copy is reused
+        again = model.get_image_crops(frame, boxes[:3], normalize=False)
     finally:
         model.crop_host_copy = "lazy"
     assert np.array_equal(np.asarray(again[2]), np.asarray(crops[2]))
@@ -244,26 +244,27 @@ def test_device_only_crops(model):
         model.device_only_crops = False
 
 
-def test_lazy_host_copies_are_bounded_and_old_crops_still_read_right(model):
-    """Lazy mode keeps the pinned host copy of the last few get_image_crops calls only (tracking._HOST_COPY_CALLS): a crop whose frame copy has been
-    retired hands out the same pixels from its pool slot, a view taken BEFORE the retirement stays valid, and the retired buffers are really released
-    (the number of live copies does not grow with the sequence)."""
+def test_lazy_host_bytes_are_fetched_on_demand_once_per_call(model):
+    """Lazy mode (round 5): get_image_crops copies NOTHING to the host; the first host read of any crop of a call fetches that call's whole batch
+    with one gather + one device->host copy (tracking.FrameHostCopy), later reads are views of it; crops of calls nobody reads never cost a
+    transfer, however long the sequence; a crop read long after its call still hands out its own pixels (busca/network.py:492-507 returns host
+    arrays: same bytes, later)."""
     from busca_amd import tracking
     model.pinned_numpy = True
     frame = synth.randint_u8(9, "frame", (540, 960, 3))
     boxes = np.array([[40 + 25 * i, 30 + 4 * i, 100 + 25 * i, 250 + 4 * i] for i in range(12)], np.float32)
     eager = np.asarray(tracking.get_image_crops(frame, boxes, normalize=False, ctx=model._ctx, host_copy="eager"))
     first = model.get_image_crops(frame, boxes, normalize=False)
-    early_view = np.asarray(first[3])                            # materialised while the copy is alive: a view into its pinned buffer
-    assert first[5].slot.host is None and first[5].slot.host_src is not None
+    src = first[5].slot.host_src[0]
+    assert first[5].slot.host is None and src._np is None            # nothing fetched yet
     keep = [first]
-    for k in range(tracking._HOST_COPY_CALLS + 3):               # later calls push the first copy out of the ring
+    for k in range(11):                                               # later calls: their crops are never read
         keep.append(model.get_image_crops(np.roll(frame, 3 * (k + 1), axis=1), boxes, normalize=False))
-    dev = model._ctx.device
-    assert len(tracking._HOST_COPIES[dev]) == tracking._HOST_COPY_CALLS
-    assert first[5].slot.host_src[0].expired and first[5].slot.host_src[0].host is None
-    assert np.array_equal(np.asarray(first[5]), eager[5])        # read from the slot
-    assert np.array_equal(early_view, eager[3]) and np.array_equal(np.asarray(first[3]), eager[3])
+    assert all(c[0].slot.host_src[0]._np is None for c in keep)
+    early_view = np.asarray(first[3])                                 # first host read: the whole batch of that call arrives
+    assert src._np is not None and src._np.shape == (12, 384, 128, 3) and keep[4][0].slot.host_src[0]._np is None
+    assert np.array_equal(early_view, eager[3])
+    assert np.array_equal(np.asarray(first[5]), eager[5]) and np.asarray(first[5]).base is src._np          # a view of the same fetch
     assert np.array_equal(np.asarray(keep[-1][2]), np.asarray(tracking.get_image_crops(np.roll(frame, 3 * len(keep[1:]), axis=1), boxes, normalize=False,
                                                                                       ctx=model._ctx, host_copy="eager"))[2])
 
