@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of a tools/gpu_profiles_r05.sh run (gpurun_out/r05/prof) into profiles/r05_* and fold the PMC traffic into profiles/pmc_traffic.json."""
+import json
+import os
+import shutil
+
+P = "gpurun_out/r05/prof/"
+d = json.load(open("profiles/pmc_traffic.json"))
+tot = [l for l in open(P + "reid_x3_512_pmc_traffic.txt") if l.startswith("TOTAL")][0].split()
+ent = d.setdefault("reid_x3_n512", {})
+ent.update({"correction": "read = FETCH_SIZE KiB x 2 (gfx950 wide-read undercount, MI355X_MICROARCH.md HBM section); write = WRITE_SIZE KiB as reported",
+            "source": "tools/pmc_traffic.sh (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, --kernel-trace only), python3 tools/reid_bench.py 512 2 x3; profiles/r05_reid_x3_512_pmc_traffic.txt",
+            "round": 5, "hbm_bytes_per_pass": (float(tot[3]) + float(tot[4])) * 1e6, "read_bytes": float(tot[3]) * 1e6, "write_bytes": float(tot[4]) * 1e6, "kernel_us_per_pass": float(tot[2])})
+json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1)
+cp = {"bench_steps20.json": "r05_bench_steps20.json", "bench_default.json": "r05_bench_default.json",
+      "reid_x3_512_timeline.txt": "r05_reid_x3_512_timeline.txt", "reid_x3_352_timeline.txt": "r05_reid_x3_352_timeline.txt",
+      "reid_x3_88_timeline.txt": "r05_reid_x3_88_timeline.txt", "reid_x3_40_timeline.txt": "r05_reid_x3_40_timeline.txt",
+      "reid_x3_512.stats.txt": "r05_reid_x3_512_kernel_stats.txt", "reid_x3_88.stats.txt": "r05_reid_x3_88_kernel_stats.txt", "reid_x3_40.stats.txt": "r05_reid_x3_40_kernel_stats.txt",
+      "dt_f32_steps20.stats.txt": "r05_dt_f32_steps20_kernel_stats.txt", "dtl_cfg5_f16.stats.txt": "r05_dtl_cfg5_f16_kernel_stats.txt", "dtl_cfg4_f32.stats.txt": "r05_dtl_cfg4_f32_kernel_stats.txt",
+      "hbm_kernels.stats.txt": "r05_hbm_kernels_kernel_stats.txt", "hbm_kernels_pmc_traffic.txt": "r05_hbm_kernels_pmc_traffic.txt", "hbm_kernels.log": "r05_hbm_kernels_table.json",
+      "reid_x3_512_sq_counters.txt": "r05_reid_x3_512_sq_counters.txt", "reid_x3_512_pmc_traffic.txt": "r05_reid_x3_512_pmc_traffic.txt",
+      "dt_f32_steps20/t_kernel_stats.csv": "r05_dt_f32_steps20_rocprof_kernel_stats.csv"}
+for a, b in cp.items():
+    if os.path.exists(P + a):
+        shutil.copy(P + a, "profiles/" + b)
+    else:
+        print("missing", a)
+for a, b in (("gpurun_out/r05/gpu_tests.txt", "profiles/r05_gpu_tests.txt"), ("gpurun_out/r05/ptail_512.txt", "profiles/r05_ubench_ptail_512.txt"),
+             ("gpurun_out/r05/lw_512.txt", "profiles/r05_ubench_loader_wave_512.txt"), ("gpurun_out/r05/lw_5.txt", "profiles/r05_ubench_loader_wave_5.txt")):
+    if os.path.exists(a):
+        shutil.copy(a, b)
