@@ -47,6 +47,9 @@ static const Case CASES[] = {
     {"stem    7x7s2 3->64         ", 512, 384, 128, 3, 64, 7, 2, X3_STEM, X3_RAW},
     {"small   3x3 64->256 bn tail ", 3, 13, 7, 64, 256, 3, 1, X3_BN, X3_RAW},
     {"small   1x1s2 128->256 plain", 5, 9, 7, 128, 256, 1, 2, X3_PLAIN, X3_RAW},
+    {"L3conv3 1x1 256->1024 bn raw", 512, 24, 8, 256, 1024, 1, 1, X3_BN, X3_RAW},
+    {"L4conv3 1x1 512->2048 bn raw", 512, 12, 4, 512, 2048, 1, 1, X3_BN, X3_RAW},
+    {"L4conv3 1x1 512->2048 bn sta", 512, 12, 4, 512, 2048, 1, 1, X3_BN, X3_STATS},
 };
 
 static unsigned long long rs = 0x9E3779B97F4A7C15ull;
