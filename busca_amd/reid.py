@@ -28,6 +28,13 @@ class ReIDEncoderHIP:
         self.ctx = ctx
         self.precision = precision
         self._blob = weights.reid_blob(state_dict, prefix)
+        if precision == "x3":
+            # the split-fp16 flavour clamps staged activations at |x| <= 1023.5; a checkpoint whose BatchNorm affines could exceed that must not be clipped silently
+            self.x3_activation_bound, where = weights.x3_activation_bound(state_dict, prefix)
+            if self.x3_activation_bound > weights.X3_OPERAND_LIMIT:
+                import warnings
+                warnings.warn("ReID checkpoint: activations of %s may reach %.0f, beyond the split-fp16 (x3) operand range of %.0f - that flavour would clip them; "
+                              "use reid_precision 'f32' (exact float32 MFMA) for this checkpoint" % (where, self.x3_activation_bound, weights.X3_OPERAND_LIMIT), RuntimeWarning)
         want = ctx.lib.busca_reid_blob_floats()
         assert self._blob.size == want, (self._blob.size, want)
         self._upload()

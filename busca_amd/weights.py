@@ -103,3 +103,36 @@ def dt_unblob(blob, d, ff, nlayers, E=512):
         off += n
     assert off == blob.size
     return out
+
+
+X3_OPERAND_LIMIT = 1023.5          # reid_x3.hip.inc: staged activations are clamped to |x| * 2^6 <= 65504 (the fp16 range)
+
+
+def x3_activation_bound(state_dict, prefix="", sigmas=48.0):
+    """Upper bound of what the split-fp16 (x3) ReID flavour stages as an MFMA operand, from the checkpoint alone.  Every conv input is either
+    relu(gamma * z + beta) with z the batch-normalised producer output (|z| <= `sigmas` standard deviations: batch statistics bound the largest
+    outlier by sqrt(pixels), real activations stay far below) or a residual-stream value = a sum of such terms (one per bottleneck of the layer plus
+    the downsample branch).  Returns (bound, where): the largest such bound over the network and the BatchNorm it comes from.  A bound above
+    X3_OPERAND_LIMIT means the kernel's clamp could clip activations SILENTLY (round-4 advisor finding); ReIDEncoderHIP warns and names `f32`."""
+    worst, where = 0.0, None
+    layer_sum = {}
+    for k, v in state_dict.items():
+        if not (k.startswith(prefix) and k.endswith(".weight")):
+            continue
+        name = k[len(prefix):-len(".weight")]
+        if not (name == "bn1" or ".bn" in name or name.endswith("downsample.1")):
+            continue
+        b = state_dict.get(prefix + name + ".bias")
+        if b is None:
+            continue
+        g, b = np.abs(_np(v)), np.abs(_np(b))
+        bound = float((g * sigmas + b).max())
+        if bound > worst:
+            worst, where = bound, name
+        if name.endswith("bn3") or name.endswith("downsample.1"):        # terms of a layer's residual stream
+            layer = name.split(".")[0]
+            layer_sum[layer] = layer_sum.get(layer, 0.0) + bound
+    for layer, tot in layer_sum.items():
+        if tot > worst:
+            worst, where = tot, layer + " residual stream"
+    return worst, where

@@ -54,7 +54,7 @@ const char* busca_build_info(void);
 /* Developer options of one context (kernel-flavour selection for A/B runs and the tests that compare flavours).  Defaults are read
  * from the environment ONCE, at busca_ctx_create (BUSCA_DT_NTRK, BUSCA_DT_TILED, BUSCA_DTL_RT, BUSCA_DTL_RT_MASK);
  * no forward reads the environment.  Names: "dt_ntrk" (0 auto / 1 / 2 tracks per workgroup of the f16 fused kernel), "dt_tiled"
- * (1 = force the layer-wise path), "dtl_rt" (0 auto / 2 / 4), "dtl_rt_mask" (-1 off), "dtl_ffn" (2 = out-proj + norm1 + feed-forward + norm2 of the layer-wise path as one kernel, 1 = feed-forward block only, 0 = one kernel per GEMM; BUSCA_DTL_FFN), "dtl_attn" (1 = QKV projection + attention of a (track, head) as one kernel where built; BUSCA_DTL_ATTN); busca_get_option also
+ * (1 = force the layer-wise path), "dtl_rt" (0 auto / 2 / 4), "dtl_rt_mask" (-1 off), "dtl_ffn" (2 = out-proj + norm1 + feed-forward + norm2 of the layer-wise path as one kernel, 1 = feed-forward block only, 0 = one kernel per GEMM; BUSCA_DTL_FFN), "dtl_attn" (1 = QKV projection + attention of a (track, head) as one kernel where built; BUSCA_DTL_ATTN), "crop_band" (1 = crops through the LDS-staged band kernel, 0 = one thread per output pixel; BUSCA_CROP_BAND); busca_get_option also
  * answers "last_dt_grid" / "last_dt_ntrk" (workgroups and tracks per workgroup of the last fused launch).  Unknown name: BUSCA_EINVAL.
  * ReID schedule knobs of a LOADED extractor (they start from the BUSCA_REID_* environment at busca_reid_load_weights and can be changed between
  * forwards): "reid_gram", "reid_halo", "reid_fuse_c1", "reid_fuse_c1_layers", "reid_fuse_c1_small", "reid_fuse_ds_layers",

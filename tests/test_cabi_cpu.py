@@ -194,3 +194,18 @@ def test_checkpoint_loading_is_strict_like_the_reference(tmp_path):
     # strict load_state_dict: missing keys raise
     with pytest.raises(RuntimeError, match="missing"):
         BUSCA(_args()).load_state_dict({"encoder.weight": sd["encoder.weight"]})
+
+
+def test_x3_activation_range_check_of_a_checkpoint():
+    """The split-fp16 ReID flavour clamps staged activations at |x| <= 1023.5 (reid_x3.hip.inc).  The bound derived from a checkpoint's BatchNorm affines
+    (weights.x3_activation_bound) is far below that for ordinary weights and trips for a BatchNorm with a huge gamma - the case ReIDEncoderHIP warns about
+    instead of clipping silently (busca/reid/resnet.py:108-128: relu(bn(.)) and the residual sum are what a conv reads)."""
+    from busca_amd import synth, weights
+    sd = dict(synth.reid_state_dict(3))
+    bound, where = weights.x3_activation_bound(sd)
+    assert 0 < bound < weights.X3_OPERAND_LIMIT, (bound, where)
+    g = sd["layer3.2.bn2.weight"].copy()
+    g[7] = 40.0
+    sd["layer3.2.bn2.weight"] = g
+    bound, where = weights.x3_activation_bound(sd)
+    assert bound > weights.X3_OPERAND_LIMIT and where == "layer3.2.bn2", (bound, where)
