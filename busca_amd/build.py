@@ -5,6 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "busca_hip.hip")
+AUX = os.path.join(HERE, "csrc", "busca_dt_aux.hip")      # instantiations that must be compiled without -amdgpu-mfma-vgpr-form (see the file)
 OUT = os.path.join(HERE, "libbusca_hip.so")
 
 
@@ -44,11 +45,18 @@ def build(force=False, verbose=False):
     # unchanged (measured A/B on MI355X, round 2).  The pass behind it is young (it crashed on an experimental variant of the
     # kernel), so a failed compile falls back to the plain flags.
     variants = [["-mllvm", "-amdgpu-mfma-vgpr-form"], []] if os.environ.get("BUSCA_NO_VGPR_FORM") is None else [[]]
-    r = None
+    aux_obj = OUT + ".aux.o"
+    cmd = [hipcc] + [f for f in _requested_flags() if f != "-shared"] + ["-c", "-o", aux_obj, AUX]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building busca_dt_aux.o")
     used = None
     for extra in variants:
         used = " ".join(base[1:] + extra)
-        cmd = base + extra + ['-DBUSCA_BUILD_FLAGS="%s"' % used, "-o", OUT + ".tmp", SRC]
+        cmd = base + extra + ['-DBUSCA_BUILD_FLAGS="%s"' % used, "-o", OUT + ".tmp", SRC, "-Wl," + aux_obj]      # (a bare .o after a .hip source is parsed as HIP source)
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -60,6 +68,7 @@ def build(force=False, verbose=False):
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("hipcc failed building libbusca_hip.so")
     os.replace(OUT + ".tmp", OUT)
+    os.remove(aux_obj)
     with open(STAMP, "w") as f:
         f.write(_stamp_request() + "\n" + used + "\n")
     return OUT

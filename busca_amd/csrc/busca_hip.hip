@@ -46,6 +46,10 @@ struct DTState {
     void* dev_tiled = nullptr;     // row-major f16 matrices (tiled path)
     DTTiledW tw;
     void* ws = nullptr; size_t ws_bytes = 0;   // tiled-path activation workspace
+    // token-split tail of the fused kernel (dt_fused_mixed_kernel): K / V exchange tiles, flags, decoder hand-over of up to xslots tracks; xepoch
+    // numbers the launches (flags only ever grow, nothing is cleared between launches); xerr is host memory the kernel writes if a wait ran out
+    void* xch = nullptr; unsigned* xflag = nullptr; float* xlg = nullptr; int* xerr = nullptr; int* xerr_dev = nullptr; int xslots = 0; unsigned xepoch = 0;
+    int num_cu = 256;
 };
 
 // Developer options of one context.  Defaults come from the environment ONCE, when the context is created; afterwards they
@@ -58,14 +62,16 @@ struct BuscaOptions {
     int dtl_ffn = 2;          // BUSCA_DTL_FFN: 2 = the layer-wise path runs out-proj + norm1 + feed-forward + norm2 as ONE kernel, 1 = the feed-forward block only,
                               // 0 = one kernel per GEMM (H and x1 through HBM)
     int dtl_attn = 1;         // BUSCA_DTL_ATTN: 1 = QKV projection + attention of a (track, head) in one kernel where it is built (0: QKV GEMM + attention kernel)
-    int dt_prof = 0;          // BUSCA_DT_PROF: phase stamps of the fused kernel (debug)
+    int dt_split = -1;        // BUSCA_DT_SPLIT: token-split tail of the fused kernel (two workgroups per track): -1 = when the last round of a launch would fill at most
+                              // half of the CUs, 0 = never, 1 = as many of the last tracks as fit one round (tests)
+    int dt_prof = 0;          // BUSCA_DT_PROF: phase stamps of the fused kernel (debug): 1 = the one-workgroup flavour, 2 = the token-split flavour (first tile's workgroup)
     int crop_band = 1;        // BUSCA_CROP_BAND: 1 = crops through the LDS-staged band kernel (crop_band_kernel), 0 = one thread per output pixel (A/B, tests)
-    int last_dt_grid = 0, last_dt_ntrk = 0;     // read-only: workgroups / tracks per workgroup of the last fused launch
+    int last_dt_grid = 0, last_dt_ntrk = 0, last_dt_split = 0;     // read-only: workgroups / tracks per workgroup / token-split tracks of the last fused launch
     static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
     void from_env() {
         dt_ntrk = env_int("BUSCA_DT_NTRK", 0); dt_tiled = getenv("BUSCA_DT_TILED") != nullptr ? 1 : 0;
         dtl_rt = env_int("BUSCA_DTL_RT", 0); dtl_rt_mask = env_int("BUSCA_DTL_RT_MASK", -1);
-        dt_prof = getenv("BUSCA_DT_PROF") != nullptr ? 1 : 0;
+        dt_prof = env_int("BUSCA_DT_PROF", 0); dt_split = env_int("BUSCA_DT_SPLIT", -1);
         dtl_ffn = env_int("BUSCA_DTL_FFN", 2); dtl_attn = env_int("BUSCA_DTL_ATTN", 1); crop_band = env_int("BUSCA_CROP_BAND", 1);
     }
 };
@@ -173,6 +179,8 @@ extern "C" int busca_set_option(busca_ctx* c, const char* name, int32_t value) {
         return fail(c, BUSCA_EINVAL, "busca_set_option: unknown option '%s'", name);
     }
     if (n == "dt_ntrk") o.dt_ntrk = value;
+    else if (n == "dt_split") o.dt_split = value;
+    else if (n == "dt_prof") o.dt_prof = value;
     else if (n == "dt_tiled") o.dt_tiled = value;
     else if (n == "dtl_rt") o.dtl_rt = value;
     else if (n == "dtl_rt_mask") o.dtl_rt_mask = value;
@@ -192,6 +200,8 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
         return fail(c, BUSCA_EINVAL, "busca_get_option: unknown option '%s'", name);
     }
     if (n == "dt_ntrk") *value = o.dt_ntrk;
+    else if (n == "dt_split") *value = o.dt_split;
+    else if (n == "last_dt_split") *value = o.last_dt_split;
     else if (n == "dt_tiled") *value = o.dt_tiled;
     else if (n == "dtl_rt") *value = o.dtl_rt;
     else if (n == "dtl_rt_mask") *value = o.dtl_rt_mask;
@@ -226,6 +236,10 @@ extern "C" void busca_ctx_destroy(busca_ctx* c) {
     if (c->dt.dev_blob) hipFree(c->dt.dev_blob);
     if (c->dt.dev_tiled) hipFree(c->dt.dev_tiled);
     if (c->dt.ws) hipFree(c->dt.ws);
+    if (c->dt.xch) hipFree(c->dt.xch);
+    if (c->dt.xflag) hipFree(c->dt.xflag);
+    if (c->dt.xlg) hipFree(c->dt.xlg);
+    if (c->dt.xerr) hipHostFree(c->dt.xerr);
     if (c->crop_fill) hipFree(c->crop_fill);
     if (c->ecc_ws) hipFree(c->ecc_ws);
     reid_free(c->reid);
@@ -404,20 +418,121 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
         S.tw.w_embed = tb + o_e;
         for (int l = 0; l < g->nlayers; ++l) { S.tw.w_in[l] = tb + oi[l]; S.tw.w_out[l] = tb + oo[l]; S.tw.w1[l] = tb + o1[l]; S.tw.w2[l] = tb + o2[l]; }
     }
+    {   // exchange buffers of the token-split tail: one round's worth of tracks (two workgroups each), sized for this width
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) S.num_cu = prop.multiProcessorCount; }
+        if (S.xch) { HIP_TRY(c, hipFree(S.xch)); S.xch = nullptr; }
+        if (S.xflag) { HIP_TRY(c, hipFree(S.xflag)); S.xflag = nullptr; }
+        if (S.xlg) { HIP_TRY(c, hipFree(S.xlg)); S.xlg = nullptr; }
+        S.xslots = S.num_cu;
+        const size_t per_slot = (size_t)2 * DT_XMAX_MT * 4 * (2 * (d / 64)) * 1024;       // parity x tile x wave x (K, V tiles of a head) x 64 lanes x 16 bytes
+        if (d % 64 == 0) {
+            HIP_TRY(c, hipMalloc(&S.xch, per_slot * S.xslots));
+            HIP_TRY(c, hipMalloc((void**)&S.xflag, (size_t)S.xslots * DT_XMAX_MT * DT_XFLAGS * sizeof(unsigned)));
+            HIP_TRY(c, hipMemset(S.xflag, 0, (size_t)S.xslots * DT_XMAX_MT * DT_XFLAGS * sizeof(unsigned)));
+            HIP_TRY(c, hipMalloc((void**)&S.xlg, (size_t)S.xslots * DT_XMAX_MT * 16 * sizeof(float)));
+            if (!S.xerr) {
+                HIP_TRY(c, hipHostMalloc((void**)&S.xerr, sizeof(int), hipHostMallocMapped)); *S.xerr = 0;
+                HIP_TRY(c, hipHostGetDevicePointer((void**)&S.xerr_dev, S.xerr, 0));
+            }
+            S.xepoch = 0;
+            HIP_TRY(c, hipDeviceSynchronize());
+        } else S.xslots = 0;
+    }
     S.loaded = true;
     return BUSCA_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// How many of the last tracks of a launch run token-split (one workgroup per 16-token tile, `parts` per track), and how many tracks share a workgroup
+// (*pair: 1 or 2).  The tracks of the last, partial round of one-track workgroups are spread over the CUs that round would leave idle: a single 32-track
+// step of three tiles runs on 96 CUs instead of 32 (0.46 -> 0.22 ms); 640 such tracks on 256 CUs are two rounds + 192 workgroups holding one tile index
+// of two tracks each (0.35 ms) instead of three rounds.  One track per workgroup is the faster flavour while its workgroups fit ONE pass over the CUs
+// (a one-tile workgroup is bound by its weight stream through the CU's vector memory path: two to a CU take twice as long); beyond that two tracks
+// share a workgroup, every streamed weight fragment feeding two tiles (f32 flavour, tracks of three tiles or more - with two tiles such a workgroup
+// would do a whole track's work).  A partial round too large for either stays one workgroup per track.
+static int dt_split_tracks(const busca_ctx* c, int B, int parts, bool can_pair, int* pair) {
+    const DTState& S = c->dt;
+    *pair = 1;
+    if (S.xslots <= 0 || c->opt.dt_split == 0 || parts > DT_XMAX_MT) return 0;
+    if (c->opt.dt_split > 0) {                // tests: 1 = one track per workgroup, 2 = two
+        *pair = (c->opt.dt_split == 2 && can_pair) ? 2 : 1;
+        return std::min(B, S.xslots / 2);
+    }
+    const int rem = B % S.num_cu;
+    if (rem == 0 || rem + 1 > S.xslots) return 0;
+    if (parts * rem <= S.num_cu) return rem;
+    if (can_pair && parts >= 3 && parts * ((rem + 1) / 2) <= S.num_cu) { *pair = 2; return rem; }
+    return 0;
+}
+
+static int dt_prof_report(busca_ctx* c, long long* d, int nwg, hipStream_t s) {
+    HIP_TRY(c, hipStreamSynchronize(s));
+    long long h[4 * DT_PROF_SLOTS];
+    HIP_TRY(c, hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipFree(d));
+    fprintf(stderr, "DT_PROF grid=%d:", nwg);
+    for (int w = 0; w < 4; ++w) {
+        fprintf(stderr, "\n w%d", w);
+        for (int i = 1; i < DT_PROF_SLOTS; ++i)
+            if (h[w * DT_PROF_SLOTS + i]) fprintf(stderr, " %d:%lld", i, h[w * DT_PROF_SLOTS + i] - h[w * DT_PROF_SLOTS]);
+    }
+    fprintf(stderr, "\n");
+    return BUSCA_OK;
+}
+
+template <int PREC, int MT, int D, int FF, int NCH, int NTRK>
+static int dt_launch_split(busca_ctx* c, const DTParams& P0, int nsplit, hipStream_t s) {
+    typedef DTLds<PREC, 1, D, FF, 512, NCH, NTRK> LD;
+    DTState& S = c->dt;
+    if (*S.xerr) return fail(c, BUSCA_EHIP, "a token-split Decision-Transformer launch gave up waiting for a partner workgroup: its results were invalid");
+    auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH, NTRK, true>;
+    const int nwg = ((nsplit + NTRK - 1) / NTRK) * MT;
+    DTParams P = P0;
+    P.nsingle = P.B - nsplit;
+    P.xepoch = ++S.xepoch; P.xch = (unsigned long long*)S.xch; P.xflag = S.xflag; P.xlg = S.xlg; P.xerr = S.xerr_dev;
+    { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
+    if (c->opt.dt_prof == 2) {
+        HIP_TRY(c, hipMalloc((void**)&P.prof, 4 * DT_PROF_SLOTS * sizeof(long long)));
+        HIP_TRY(c, hipMemset(P.prof, 0, 4 * DT_PROF_SLOTS * sizeof(long long)));
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LD::TOTAL, s, P);
+        return dt_prof_report(c, P.prof, nwg, s);
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LD::TOTAL, s, P);
+    return BUSCA_OK;
+}
+
 template <int PREC, int MT, int D, int FF, int NCH, int NTRK = 1>
 static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
     typedef DTLds<PREC, MT, D, FF, 512, NCH, NTRK> LD;
     static_assert(LD::TOTAL <= 160 * 1024, "LDS plan exceeds the 160 KiB of a CU");
     auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH, NTRK>;
     const int nwg = (P.B + NTRK - 1) / NTRK;
-    c->opt.last_dt_grid = nwg; c->opt.last_dt_ntrk = NTRK;
+    c->opt.last_dt_grid = nwg; c->opt.last_dt_ntrk = NTRK; c->opt.last_dt_split = 0;
+    if constexpr (MT >= 2 && MT <= DT_XMAX_MT && NTRK == 1) {
+        constexpr bool PAIR = PREC == 0;        // the two-tracks-per-workgroup split flavour is built for f32 (f16 has its own two-track flavour for throughput)
+        // (every flavour is configured by the first forward of a shape, whichever it takes: a later launch of another track count must not pay for it)
+        if (c->dt.xslots > 0) {
+            { int rc = ensure_lds(c, (const void*)dt_fused_kernel<PREC, MT, D, FF, 512, NCH, 1, true>, DTLds<PREC, 1, D, FF, 512, NCH, 1>::TOTAL); if (rc) return rc; }
+            if constexpr (PAIR) { int rc = ensure_lds(c, (const void*)dt_fused_kernel<PREC, MT, D, FF, 512, NCH, 2, true>, DTLds<PREC, 1, D, FF, 512, NCH, 2>::TOTAL); if (rc) return rc; }
+        }
+        { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
+        // whole rounds of one-track workgroups, then the tail's tracks one token tile per workgroup: ONE timed region (the step batch), two launches on the stream
+        int pair = 1;
+        const int nsplit = c->opt.dt_prof == 1 ? 0 : dt_split_tracks(c, P.B, MT, PAIR, &pair);
+        if (nsplit > 0) {
+            c->opt.last_dt_grid = P.B - nsplit + ((nsplit + pair - 1) / pair) * MT; c->opt.last_dt_split = nsplit; c->opt.last_dt_ntrk = pair;
+            TimedLaunch tl(c, s);
+            if (P.B > nsplit) hipLaunchKernelGGL(kern, dim3(P.B - nsplit), dim3(256), LD::TOTAL, s, P);
+            int rc = BUSCA_OK;
+            if constexpr (PAIR) { if (pair == 2) rc = dt_launch_split<PREC, MT, D, FF, NCH, 2>(c, P, nsplit, s); else rc = dt_launch_split<PREC, MT, D, FF, NCH, 1>(c, P, nsplit, s); }
+            else rc = dt_launch_split<PREC, MT, D, FF, NCH, 1>(c, P, nsplit, s);
+            if (rc) return rc;
+            HIP_TRY(c, hipGetLastError());
+            return BUSCA_OK;
+        }
+    }
     { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
-    const bool prof = c->opt.dt_prof != 0;   // debug: phase timestamps of workgroup 0
+    const bool prof = c->opt.dt_prof == 1;   // debug: phase timestamps of workgroup 0
     if (prof) {
         DTParams Q = P;
         long long* d = nullptr;
@@ -425,18 +540,7 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
         HIP_TRY(c, hipMemset(d, 0, 4 * DT_PROF_SLOTS * sizeof(long long)));
         Q.prof = d;
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LD::TOTAL, s, Q);
-        HIP_TRY(c, hipStreamSynchronize(s));
-        long long h[4 * DT_PROF_SLOTS];
-        HIP_TRY(c, hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipFree(d));
-        fprintf(stderr, "DT_PROF grid=%d:", nwg);
-        for (int w = 0; w < 4; ++w) {
-            fprintf(stderr, "\n w%d", w);
-            for (int i = 1; i < DT_PROF_SLOTS; ++i)
-                if (h[w * DT_PROF_SLOTS + i]) fprintf(stderr, " %d:%lld", i, h[w * DT_PROF_SLOTS + i] - h[w * DT_PROF_SLOTS]);
-        }
-        fprintf(stderr, "\n");
-        return BUSCA_OK;
+        return dt_prof_report(c, d, nwg, s);
     }
     {
         TimedLaunch tl(c, s);

@@ -151,6 +151,7 @@ def test_two_tracks_per_workgroup_flavour(ctx, shape):
     # the flavour is a per-context option read at every call (busca_set_option), NOT an environment variable latched by the first
     # forward of the process; the launch geometry is read back so that this comparison can never silently compare a run with itself
     try:
+        ctx.set_option("dt_split", 0)       # (the token-split tail has its own test below)
         ctx.set_option("dt_ntrk", 1)
         one, _ = _run(ctx, sd, inp, "f16", True, want_hidden=True, want_att=True)
         assert ctx.get_option("last_dt_ntrk") == 1 and ctx.get_option("last_dt_grid") == B
@@ -162,6 +163,7 @@ def test_two_tracks_per_workgroup_flavour(ctx, shape):
             assert ctx.get_option("last_dt_ntrk") == 1
     finally:
         ctx.set_option("dt_ntrk", 0)
+    ctx.set_option("dt_split", 0)
     if d == 256:
         assert not np.array_equal(one["logits"], two["logits"])          # two different kernels really ran
     # measured on MI355X once the comparison was real (round 3): logits differ by up to 3.1e-3, i.e. f16 rounding of operands
@@ -179,6 +181,56 @@ def test_two_tracks_per_workgroup_flavour(ctx, shape):
         want_two = ((B + 511) // 512) * 188 <= ((B + 255) // 256) * 100
         assert ctx.get_option("last_dt_ntrk") == (2 if want_two else 1)
         assert np.array_equal(auto["logits"], (two if want_two else one)["logits"])
+    ctx.set_option("dt_split", -1)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("pair", [1, 2], ids=["one-track", "two-tracks"])
+@pytest.mark.parametrize("shape", [(32, 11, 16, 256), (5, 11, 5, 256), (100, 11, 5, 512), (1, 11, 5, 512), (37, 9, 4, 64), (200, 11, 16, 256), (9, 11, 24, 64)])
+def test_token_split_tail_is_bit_identical(ctx, prec, pair, shape):
+    """Round 5: a track on SEVERAL workgroups (one 16-token tile each; K / V tiles of every layer exchanged through agent-scope stores under per-wave
+    flags, dt_fused_kernel<..., SPLIT>) - the flavour that runs the tail of a launch whose last round would leave most CUs idle; a workgroup holds the
+    tile of one track, or the same tile of two tracks (f32: every streamed weight fragment then feeds two tiles).  Every token sees the same products in
+    the same order as in the one-workgroup flavour: logits, probabilities, argmax, hidden states and attention maps are bit-identical, whatever mix of
+    flavours a launch uses (forced split of the last min(B, 128) tracks against no split; odd counts: the last workgroup's second track is a recomputation)."""
+    B, L, P, d = shape
+    if pair == 2 and prec == "f16":
+        pytest.skip("the two-track split flavour is built for f32")
+    seed = 900 + B + d
+    sd = synth.dt_state_dict(seed, d=d, ff=2 * d)
+    inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)
+    try:
+        ctx.set_option("dt_ntrk", 1)
+        ctx.set_option("dt_split", 0)
+        one, _ = _run(ctx, sd, inp, prec, True, want_hidden=True, want_att=True)
+        assert ctx.get_option("last_dt_split") == 0 and ctx.get_option("last_dt_grid") == B
+        ctx.set_option("dt_split", pair)
+        two, _ = _run(ctx, sd, inp, prec, True, want_hidden=True, want_att=True)
+        ns, tiles = min(B, 128), (L + 2 * (P + 2) + 15) // 16
+        assert tiles >= 2 and ctx.get_option("last_dt_split") == ns and ctx.get_option("last_dt_ntrk") == pair
+        assert ctx.get_option("last_dt_grid") == B - ns + tiles * ((ns + pair - 1) // pair)
+        for _ in range(3):          # flags only ever grow: a re-run on the same exchange buffers must not see the previous launch's tiles as ready
+            again, _ = _run(ctx, sd, inp, prec, True, want_hidden=True, want_att=True)
+            assert np.array_equal(again["logits"], two["logits"])
+    finally:
+        ctx.set_option("dt_ntrk", 0)
+        ctx.set_option("dt_split", -1)
+    for k in ("logits", "probs", "argmax", "hidden", "att"):
+        assert np.array_equal(one[k], two[k]), k
+
+
+def test_token_split_tail_policy(ctx):
+    """Which launches take the split tail by default (256 CUs, 47 tokens = three tiles): the tracks of the last, partial round - one track per workgroup
+    while three workgroups per track fit one pass over the CUs (85 tracks), two tracks per workgroup while those fit (170 tracks), else no split."""
+    sd = synth.dt_state_dict(5, d=256, ff=512)
+    want = {32: (32, 96), 85: (85, 255), 86: (86, 129), 128: (128, 192), 129: (129, 195), 170: (170, 255), 171: (0, 171), 256: (0, 256), 300: (44, 256 + 132),
+            450: (0, 450), 640: (128, 512 + 192), 641: (129, 512 + 195)}
+    for B, (ns, grid) in want.items():
+        inp = synth.dt_inputs(5, B, 11, 16)
+        out, _ = _run(ctx, sd, inp, "f32", True)
+        assert ctx.get_option("last_dt_split") == ns, (B, ctx.get_option("last_dt_split"))
+        assert ctx.get_option("last_dt_grid") == grid, (B, ctx.get_option("last_dt_grid"))
+        assert (out["argmax"] == out["probs"].argmax(-1)).all()
 
 
 # ---- the non-shipped token layouts (network.py:103-165, encodings.py:112-146) ---------------------------------------------------
