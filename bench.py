@@ -135,6 +135,16 @@ class DTRunner:
         lib.busca_timing_enable(h, 0)
         return avg.value * n.value, n.value, calls, k
 
+    def geometry(self):
+        """Launch geometry of the last forward: workgroups, and how many of its tracks ran token-split (one 16-token tile per workgroup: the tracks of
+        a last, partial round of one-track workgroups - a second launch inside the same bracketed region)."""
+        g = {k: int(self.ctx.get_option(o)) for k, o in (("workgroups", "last_dt_grid"), ("token_split_tracks", "last_dt_split"), ("tracks_per_workgroup", "last_dt_ntrk"))}
+        if g["token_split_tracks"] == 0:
+            g.pop("token_split_tracks")
+        else:
+            g["tracks_per_split_workgroup"] = g.pop("tracks_per_workgroup")
+        return g
+
     def p50_latency_ms(self, samples):
         if samples <= 0:
             return None
@@ -150,7 +160,7 @@ class DTRunner:
         return float(np.percentile(np.array(lat), 50) * 1e3)
 
 
-def roofline_obj(precision, B, L, P, d, ff, timing, bracket_ms_per_call, kernel="dt_fused_kernel"):
+def roofline_obj(precision, B, L, P, d, ff, timing, bracket_ms_per_call, kernel="dt_fused_kernel", geometry=None):
     """timing = DTRunner.kernel_time(...).  achieved = algorithmic FLOPs of the steps those launches REALLY processed / the
     kernel time they took (a 6-step launch counts 6 steps)."""
     tot_ms, nk, calls, steps = timing
@@ -166,7 +176,11 @@ def roofline_obj(precision, B, L, P, d, ff, timing, bracket_ms_per_call, kernel=
         traffic_note = ent["source"] if ent else "no PMC run of this launch shape (%s, %.2f steps per launch) in profiles/pmc_traffic.json" % (key, spl)
     except Exception as e:
         traffic, traffic_note = None, "profiles/pmc_traffic.json unreadable: %r" % (e,)
-    return {"bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[precision],
+    if geometry and geometry.get("token_split_tracks"):
+        kernel += " (two launches in one bracketed region: <SPLIT=false> for the whole rounds of one-track workgroups + <SPLIT=true> for the %d tracks of the last round, one token tile per workgroup)" % geometry["token_split_tracks"]
+    extra = {"frac_of_f32_mfma_peak": ach / PEAK_TFLOPS["f32"],
+             "peak_note": "x3 = float32-equivalent GEMMs as three fp16 MFMAs per product block: peak = the dense fp16 MFMA peak / 3 (the 4 % of the FLOPs in the attention run on the f32 MFMA)"} if precision == "x3" else {}
+    return {**extra, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[precision], "launch_geometry": geometry,
             "traffic": traffic, "traffic_note": traffic_note, "kernel": kernel, "kernel_avg_ms": tot_ms / max(1, nk), "kernel_launches_per_call": nk / max(1, calls),
             "kernel_ms_per_call": tot_ms / max(1, calls), "flops_per_call": flops / max(1, calls),
             "steps_per_launch": spl, "event_bracket_ms_per_launch": bracket_ms_per_call,
@@ -193,7 +207,8 @@ def config_leg(ctx, dev, name, B, L, P, d, precision, F, steps, seed=7):
             "value": steps / el, "unit": "steps/s", "steps": steps, "ms_per_step": el / steps * 1e3, "steps_in_flight_per_launch": F,
             "path": "fused (one kernel per call)" if fused else "layer-wise (%d kernels per call)" % round(timing[1] / max(1, timing[2])),
             "roofline": roofline_obj(precision, B, L, P, d, ff, timing, el / calls * 1e3,
-                                     kernel="dt_fused_kernel" if fused else "dt_bucket_ids + dtl_gemm<EMBED> + 4 x (dtl_qkv_attn + dtl_ffn) + dtl_decoder (whole forward, every launch bracketed)")}
+                                     kernel="dt_fused_kernel" if fused else "dt_bucket_ids + dtl_gemm<EMBED> + 4 x (dtl_qkv_attn + dtl_ffn) + dtl_decoder (whole forward, every launch bracketed)",
+                                     geometry=run.geometry() if fused else None)}
 
 
 def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None, reid_precision="f16"):
@@ -267,7 +282,7 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None, reid_precision="
 def assoc_e2e(frames):
     """Simulated tracker frame (tools/e2e_sim.py): crops cut on the GPU, device-resident track memory, centre distances,
     BUSCA.associate_embeddings on the SHIPPED model shape (d=512, L=11, P=5; config/*/*/*.yml) - the metric's
-    'p50 assoc latency'.  The UNPREFIXED keys are what a user gets by default (busca_amd.network.BUSCA: float32 Decision Transformer +
+    'p50 assoc latency'.  The UNPREFIXED keys are what a user gets by default (busca_amd.network.BUSCA: float32-equivalent x3 Decision Transformer +
     float32-equivalent x3 ReID); `f16_*` = the opt-in fast flavours (fp16 ReID + f16 DT), `f32_*` = exact-f32 ReID + f32 DT."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gc
@@ -275,7 +290,7 @@ def assoc_e2e(frames):
     out = {}
     keys = ("p50_assoc_latency_ms", "p50_crop_ms", "p50_center_distance_ms", "busca_frames_per_s", "device_resident_crops", "precision", "reid_precision")
     for lost, objs in ((32, 150), (8, 60)):
-        r = e2e_sim.run(lost, objs, 5, 512, frames=frames, verbose=False)            # library defaults: precision f32, reid_precision x3
+        r = e2e_sim.run(lost, objs, 5, 512, frames=frames, verbose=False)            # library defaults: precision x3, reid_precision x3
         out["lost%d_dets%d" % (lost, objs - lost)] = {k: r[k] for k in keys}
         gc.collect(); torch.cuda.empty_cache()      # the previous scenes' models / crop pools go away before the next one is timed
     try:        # opt-in fast flavours: fp16 ReID + f16 Decision Transformer (moves probabilities by up to 0.03, profiles/r04_decision_agreement.json)
@@ -445,8 +460,9 @@ def main():
     ap.add_argument("--proposals", type=int, default=16, help="proposals per track (P)")
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--seq-len", type=int, default=11)
-    ap.add_argument("--precision", choices=["f32", "f16"], default=os.environ.get("BUSCA_BENCH_PRECISION", "f32"),
-                    help="MFMA operand type of the primary line; the other one is reported under `variants`")
+    ap.add_argument("--precision", choices=["x3", "f32", "f16"], default=os.environ.get("BUSCA_BENCH_PRECISION", "x3"),
+                    help="arithmetic of the primary line (default: the library's default flavour, x3 = float32-equivalent GEMMs as three fp16 MFMAs per "
+                         "product block; f32 = exact float32 MFMA); the others are reported under `variants`")
     ap.add_argument("--inflight", type=int, default=0,
                     help="independent steps handed to one C-ABI call; 0 = automatic: the K timed steps as ceil(K/64) launches of "
                          "near-equal size, so a short run is ONE launch whose workgroups back-fill the CUs round after round")
@@ -533,6 +549,7 @@ def main():
 
     # ---- roofline leg: the same launches, each bracketed by HIP events on the launch stream -------------------
     timing = run.kernel_time(min(args.steps, 50 * F))
+    geom = run.geometry()
     if not timing[1]:
         timing = (ev_ms, n_launch, n_launch, args.steps)
     p50 = run.p50_latency_ms(args.latency_samples)
@@ -555,42 +572,56 @@ def main():
             "value": total_steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "dtype_note": {"x3": "float32-equivalent: every GEMM product block is three fp16 MFMAs on operands split into fp16 hi + lo (22 mantissa bits), f32 accumulate; attention, "
+                                 "LayerNorm, softmax and the residual stream in f32 - logits 1e-5 from the exact-f32 flavour (`variants.f32`), same parity bars",
+                           "f32": "exact float32 MFMA (v_mfma_f32_16x16x4_f32)", "f16": "fp16 operands, f32 accumulate (opt-in)"}[args.precision],
             "p50_latency_ms": p50,
             "config": {"workload": "cfgN DT-step: %d lost x %d proposals x d%d (L=%d, T=%d, ff=%d, 4 layers, 4 heads), ReID features "
                                    "precomputed; BASELINE.json configs[1]-shaped batch without the tracker" % (B, P, d, L, L + 2 * (P + 2), ff),
                        "lost": B, "proposals": P, "d": d, "seq_len": L, "steps_in_flight_per_launch": F, "launches_in_timed_region": n_launch,
                        "parallelism": "independent sequences sharded per GPU, no collective (%d rank%s)%s" % (
                            world, "" if world == 1 else "s", "" if backend == "nccl" else "; TEST MODE backend=%s, ranks share %d GPU(s)" % (backend, ndev))},
-            "roofline": roofline_obj(args.precision, B, L, P, d, ff, timing, ev_ms / max(1, n_launch)),
+            "roofline": roofline_obj(args.precision, B, L, P, d, ff, timing, ev_ms / max(1, n_launch), geometry=geom),
             "ranks": ranks,
         }
         if split is not None:
             result["configs"] = {"cfg5_split": split}
     # ---- secondary precision + full step (rank 0, outside the contract's timed region) ---------------------------
     if rank == 0 and not args.no_variants:
-        other = "f16" if args.precision == "f32" else "f32"
-        # the f16 flavour packs two tracks per workgroup from 257 tracks on: give it two rounds of workgroups (16 steps)
-        F2 = 16 if other == "f16" else 8
-        big2 = synth.dt_inputs(seed + 1000 * rank, B * F2, L, P)
-        tens2 = {k: torch.from_numpy(v).to(dev) for k, v in big2.items()}
-        r2 = DTRunner(ctx, sd, other, tens2, B, L, P, F2, dev)
-        k2 = 1600                 # this leg is outside the contract's timed region: its own step count, whole launches only
-        r2.run_steps(160)
-        torch.cuda.synchronize(dev)
-        a = time.perf_counter()
-        nl2 = r2.run_steps(k2)
-        torch.cuda.synchronize(dev)
-        el2 = time.perf_counter() - a
-        tm2 = r2.kernel_time(min(k2, 50 * F2))
-        if not tm2[1]:
-            tm2 = (el2 * 1e3, nl2, nl2, k2)
-        result["variants"] = {other: {"value": k2 / el2, "unit": "steps/s", "steps": k2, "n_gpus": 1, "dtype": other, "steps_in_flight_per_launch": F2,
-                                      "p50_latency_ms": r2.p50_latency_ms(min(args.latency_samples, 300)),
-                                      "roofline": roofline_obj(other, B, L, P, d, ff, tm2, el2 / nl2 * 1e3)}}
+        result["variants"] = {}
+        r2 = None
+        for other in [q for q in ("f32", "x3", "f16") if q != args.precision]:
+            # the f16 flavour packs two tracks per workgroup from 257 tracks on: give it two rounds of workgroups (16 steps)
+            F2 = 16 if other == "f16" else 8
+            big2 = synth.dt_inputs(seed + 1000 * rank, B * F2, L, P)
+            tens2 = {k: torch.from_numpy(v).to(dev) for k, v in big2.items()}
+            rv = DTRunner(ctx, sd, other, tens2, B, L, P, F2, dev)
+            k2 = 1600                 # these legs are outside the contract's timed region: their own step count, whole launches only
+            rv.run_steps(160)
+            torch.cuda.synchronize(dev)
+            a = time.perf_counter()
+            nl2 = rv.run_steps(k2)
+            torch.cuda.synchronize(dev)
+            el2 = time.perf_counter() - a
+            tm2 = rv.kernel_time(min(k2, 50 * F2))
+            if not tm2[1]:
+                tm2 = (el2 * 1e3, nl2, nl2, k2)
+            result["variants"][other] = {"value": k2 / el2, "unit": "steps/s", "steps": k2, "n_gpus": 1, "dtype": other, "steps_in_flight_per_launch": F2,
+                                         "p50_latency_ms": rv.p50_latency_ms(min(args.latency_samples, 300)),
+                                         "roofline": roofline_obj(other, B, L, P, d, ff, tm2, el2 / nl2 * 1e3, geometry=rv.geometry())}
+            if other == "f16":
+                r2 = rv
+            if other == "f32":      # the exact flavour at the driver's step count too (one launch of 20 steps: two whole rounds + the token-split tail)
+                t20 = synth.dt_inputs(seed + 1000 * rank, B * 20, L, P)
+                r20 = DTRunner(ctx, sd, "f32", {k: torch.from_numpy(v).to(dev) for k, v in t20.items()}, B, L, P, 20, dev)
+                r20.run_steps(40)
+                tm20 = r20.kernel_time(200)
+                result["variants"]["f32_steps20"] = {"dtype": "f32", "steps_in_flight_per_launch": 20, "value": 200 / (tm20[0] * 1e-3) if tm20[0] > 0 else None, "unit": "steps/s (kernel time)",
+                                                     "roofline": roofline_obj("f32", B, L, P, d, ff, tm20, tm20[0] / max(1, tm20[2]), geometry=r20.geometry())}
         # the other BASELINE shapes as their own DT-step lines (cfgR = shipped model shape; cfg4 = BASELINE configs[3];
         # cfg5 = BASELINE configs[4], one GPU's share is the full 512-track step here)
         cfgs = result.setdefault("configs", {})
-        for name, cB, cP, cd, prec, cF, csteps in (("cfgR", 32, 5, 512, "f32", 8, 400), ("cfgR_f16", 32, 5, 512, "f16", 8, 800),
+        for name, cB, cP, cd, prec, cF, csteps in (("cfgR", 32, 5, 512, "x3", 8, 600), ("cfgR_f32", 32, 5, 512, "f32", 8, 400), ("cfgR_f16", 32, 5, 512, "f16", 8, 800),
                                                    ("cfg4", 128, 32, 512, "f32", 2, 20), ("cfg4_f16", 128, 32, 512, "f16", 2, 60),
                                                    ("cfg5", 512, 64, 512, "f16", 1, 20)):
             try:
@@ -600,7 +631,7 @@ def main():
         try:        # BASELINE configs[3] as a FULL step (crops cut on the GPU, 1 408 + 4 096-crop BatchNorm batches, DT at T = 79)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import cfg4_step
-            cfgs["cfg4_full_step"] = cfg4_step.run(3, "f32", reid_precision="x3")               # library defaults (x3 ReID + f32 DT)
+            cfgs["cfg4_full_step"] = cfg4_step.run(3, "x3", reid_precision="x3")               # library defaults (x3 ReID + x3 DT; T = 79 runs the exact f32 layer-wise path)
             cfgs["cfg4_full_step_f16"] = cfg4_step.run(3, "f16", reid_precision="f16")          # opt-in fast flavours
             cfgs["cfg4_full_step_f16_expanded_batch"] = cfg4_step.run(3, "f16", dedup=False, reid_precision="f16")
         except Exception as e:
@@ -612,10 +643,10 @@ def main():
         if args.full_steps > 0:
             from busca_amd.dt import DecisionTransformerHIP
             # UNPREFIXED `full_step` = the library's default flavour: float32-EQUIVALENT ReID on the fp16 matrix cores (BUSCA_PREC_F16X3: same parity bars as the
-            # exact flavour, tests/test_reid_gpu.py EXACT_FLAVOURS) + the f32 Decision Transformer.  Its own context: a busca_ctx holds one ReID weight set.
+            # exact flavour, tests/test_reid_gpu.py EXACT_FLAVOURS) + the float32-equivalent (x3) Decision Transformer.  Its own context: a busca_ctx holds one ReID weight set.
             try:
                 ctx3 = _lib.Context(dev_index)
-                dt3 = DecisionTransformerHIP(ctx3, sd, activation="relu", fake_bbox_f64=True, precision="f32")
+                dt3 = DecisionTransformerHIP(ctx3, sd, activation="relu", fake_bbox_f64=True, precision="x3")
                 result["full_step"] = full_step(ctx3, dt3, B, L, P, args.full_steps, dev, reid_precision="x3")
                 result["full_step_tracker_like_candidates"] = full_step(ctx3, dt3, B, L, P, args.full_steps, dev, n_det=118, reid_precision="x3")
                 ctx3.close()
@@ -623,7 +654,7 @@ def main():
                 result["full_step"] = {"error": repr(e)}
             # opt-in fast flavours: fp16 ReID + f16 Decision Transformer
             try:
-                dt16 = r2.model if other == "f16" else DTRunner(ctx, sd, "f16", tens, B, L, P, 1, dev).model
+                dt16 = r2.model if r2 is not None else DTRunner(ctx, sd, "f16", tens, B, L, P, 1, dev).model
                 result["full_step_f16"] = full_step(ctx, dt16, B, L, P, args.full_steps, dev)
                 result["full_step_f16_tracker_like_candidates"] = full_step(ctx, dt16, B, L, P, args.full_steps, dev, n_det=118)
             except Exception as e:

@@ -288,7 +288,7 @@ static bool dt_cfg_ok(const busca_dt_cfg* g) {
     const int hd = g->d / g->nhead;
     if (!(hd == 16 || hd == 32 || hd == 64 || hd == 128)) return false;             // head widths the attention kernels are built for
     if (g->E != 512 || g->ff < g->d || g->ff % g->d != 0 || g->ff > 8 * g->d) return false;   // ff = k d: whole column blocks of the layer-wise GEMM
-    if (g->precision != BUSCA_PREC_F32 && g->precision != BUSCA_PREC_F16) return false;
+    if (g->precision != BUSCA_PREC_F32 && g->precision != BUSCA_PREC_F16 && g->precision != BUSCA_PREC_F16X3) return false;
     if (g->layout & ~(BUSCA_LAYOUT_CAN_FIRST | BUSCA_LAYOUT_NO_BAD | BUSCA_LAYOUT_SEP_AS_CAN)) return false;
     return true;
 }
@@ -304,7 +304,29 @@ extern "C" size_t busca_dt_blob_floats(const busca_dt_cfg* g) {
 
 // Pack W[N][K] (row-major f32) into MFMA operand-fragment order: for (row tile nt, chunk kc) 64 lanes x 16 B,
 // lane (a = lane&15, kb = lane>>4) = W[16nt + a][kc*CHUNK + kb*SUB .. +SUB).  Returns bytes written.
+// BUSCA_PREC_F16X3: per (nt, kc) the 64 hi fragments, then the 64 lo fragments, of DT_X3_WS * W split as hi = fp16(x), lo = fp16(x - hi).
 static size_t pack_matrix(const float* W, int N, int K, int prec, unsigned char* dst) {
+    if (prec == BUSCA_PREC_F16X3) {
+        const int NT = N / 16, KC = K / 32;
+        size_t off = 0;
+        for (int nt = 0; nt < NT; ++nt)
+            for (int kc = 0; kc < KC; ++kc) {
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int a = lane & 15, kb = lane >> 4;
+                    const float* src = W + (size_t)(16 * nt + a) * K + kc * 32 + kb * 8;
+                    _Float16 h[8], l[8];
+                    for (int i = 0; i < 8; ++i) {
+                        float x = src[i] * DT_X3_WS;
+                        x = x > 65504.f ? 65504.f : (x < -65504.f ? -65504.f : x);
+                        h[i] = (_Float16)x; l[i] = (_Float16)(x - (float)h[i]);
+                    }
+                    memcpy(dst + off + (size_t)lane * 16, h, 16);
+                    memcpy(dst + off + 1024 + (size_t)lane * 16, l, 16);
+                }
+                off += 2048;
+            }
+        return off;
+    }
     const int chunk = prec == BUSCA_PREC_F32 ? 16 : 32, sub = chunk / 4;
     const int NT = N / 16, KC = K / chunk;
     size_t off = 0;
@@ -333,13 +355,20 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
     if (!lut_xy || !lut_sz || !lut_t || lut_c <= 0 || 3 * lut_c < g->d) return fail(c, BUSCA_EINVAL, "bad encoding LUTs");
     HIP_TRY(c, hipSetDevice(c->device));
     const int d = g->d, E = g->E, ff = g->ff, prec = g->precision;
-    const size_t es = prec == BUSCA_PREC_F32 ? 4 : 2;
+    const size_t es = prec == BUSCA_PREC_F16 ? 2 : 4;      // (x3: two fp16 planes)
     // host staging buffer, everything 256-byte aligned
     std::vector<unsigned char> host;
     auto reserve = [&](size_t bytes) { size_t off = (host.size() + 255) & ~(size_t)255; host.resize(off + bytes); return off; };
     const float* cur = blob;
     auto take = [&](size_t n) { const float* p = cur; cur += n; return p; };
     auto put_vec = [&](const float* src, size_t n) { size_t off = reserve(n * 4); memcpy(host.data() + off, src, n * 4); return off; };
+    if (prec == BUSCA_PREC_F16X3) {
+        // the split-fp16 flavour carries weights as DT_X3_WS * w in fp16 hi + lo: a checkpoint beyond that range must not be clipped silently
+        float wmax = 0.f;
+        for (size_t i = 0; i < blob_floats; ++i) wmax = std::max(wmax, std::fabs(blob[i]));
+        if (!(wmax * DT_X3_WS <= 65504.f))
+            return fail(c, BUSCA_EINVAL, "Decision-Transformer weights reach |w| = %g, beyond the split-fp16 (BUSCA_PREC_F16X3) operand range of %g: load them with BUSCA_PREC_F32", (double)wmax, 65504.0 / DT_X3_WS);
+    }
     auto put_mat = [&](const float* src, int N, int K) { size_t off = reserve((size_t)N * K * es); pack_matrix(src, N, K, prec, host.data() + off); return off; };
 
     struct Offs { size_t w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2; } lo[DT_MAX_LAYERS];
@@ -399,7 +428,7 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
             while (hw.size() % 16) hw.push_back(0);
             const size_t off = hw.size();
             hw.resize(off + n * es);
-            if (prec == BUSCA_PREC_F32) memcpy(hw.data() + off, src, n * 4);
+            if (prec != BUSCA_PREC_F16) memcpy(hw.data() + off, src, n * 4);      // (x3: shapes beyond the fused kernel run the exact f32 layer-wise path)
             else { _Float16* d16 = (_Float16*)(hw.data() + off); for (size_t i = 0; i < n; ++i) d16[i] = (_Float16)src[i]; }
             return off;
         };
@@ -450,7 +479,7 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
 // (a one-tile workgroup is bound by its weight stream through the CU's vector memory path: two to a CU take twice as long); beyond that two tracks
 // share a workgroup, every streamed weight fragment feeding two tiles (f32 flavour, tracks of three tiles or more - with two tiles such a workgroup
 // would do a whole track's work).  A partial round too large for either stays one workgroup per track.
-static int dt_split_tracks(const busca_ctx* c, int B, int parts, bool can_pair, int* pair) {
+static int dt_split_tracks(const busca_ctx* c, int B, int parts, bool by_default, bool can_pair, int* pair) {
     const DTState& S = c->dt;
     *pair = 1;
     if (S.xslots <= 0 || c->opt.dt_split == 0 || parts > DT_XMAX_MT) return 0;
@@ -458,10 +487,13 @@ static int dt_split_tracks(const busca_ctx* c, int B, int parts, bool can_pair, 
         *pair = (c->opt.dt_split == 2 && can_pair) ? 2 : 1;
         return std::min(B, S.xslots / 2);
     }
+    // (f16 is left alone: that kernel is bound by the weight stream, which every workgroup of a split track repeats - measured 0.083 vs 0.085 ms for a
+    // 32-track step, slower from one pass of workgroups on)
+    if (!by_default) return 0;
     const int rem = B % S.num_cu;
     if (rem == 0 || rem + 1 > S.xslots) return 0;
     if (parts * rem <= S.num_cu) return rem;
-    if (can_pair && parts >= 3 && parts * ((rem + 1) / 2) <= S.num_cu) { *pair = 2; return rem; }
+    if (can_pair && parts * ((rem + 1) / 2) <= S.num_cu) { *pair = 2; return rem; }
     return 0;
 }
 
@@ -509,7 +541,7 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
     const int nwg = (P.B + NTRK - 1) / NTRK;
     c->opt.last_dt_grid = nwg; c->opt.last_dt_ntrk = NTRK; c->opt.last_dt_split = 0;
     if constexpr (MT >= 2 && MT <= DT_XMAX_MT && NTRK == 1) {
-        constexpr bool PAIR = PREC == 0;        // the two-tracks-per-workgroup split flavour is built for f32 (f16 has its own two-track flavour for throughput)
+        constexpr bool PAIR = PREC != 1 && MT >= 3;       // the two-tracks-per-workgroup split flavour: f32 / x3, three tiles or more (with two tiles it would do a whole track's work)
         // (every flavour is configured by the first forward of a shape, whichever it takes: a later launch of another track count must not pay for it)
         if (c->dt.xslots > 0) {
             { int rc = ensure_lds(c, (const void*)dt_fused_kernel<PREC, MT, D, FF, 512, NCH, 1, true>, DTLds<PREC, 1, D, FF, 512, NCH, 1>::TOTAL); if (rc) return rc; }
@@ -518,7 +550,7 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
         { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
         // whole rounds of one-track workgroups, then the tail's tracks one token tile per workgroup: ONE timed region (the step batch), two launches on the stream
         int pair = 1;
-        const int nsplit = c->opt.dt_prof == 1 ? 0 : dt_split_tracks(c, P.B, MT, PAIR, &pair);
+        const int nsplit = c->opt.dt_prof == 1 ? 0 : dt_split_tracks(c, P.B, MT, PREC != 1, PAIR, &pair);
         if (nsplit > 0) {
             c->opt.last_dt_grid = P.B - nsplit + ((nsplit + pair - 1) / pair) * MT; c->opt.last_dt_split = nsplit; c->opt.last_dt_ntrk = pair;
             TimedLaunch tl(c, s);
@@ -751,7 +783,7 @@ extern "C" int busca_dt_reserve(busca_ctx* c, int32_t B, int32_t L, int32_t P, v
     if (!c) return BUSCA_EINVAL;
     if (!c->dt.loaded) return fail(c, BUSCA_ENOWEIGHTS, "busca_dt_reserve before busca_dt_load_weights");
     if (B < 0 || L < 1 || P < 1) return fail(c, BUSCA_EINVAL, "bad shape B=%d L=%d P=%d", B, L, P);
-    const size_t es = c->dt.cfg.precision == BUSCA_PREC_F32 ? 4 : 2;
+    const size_t es = c->dt.cfg.precision == BUSCA_PREC_F16 ? 2 : 4;
     return dtl_ws_ensure(c, dtl_ws_bytes((size_t)B * (L + 2 * (P + c->dt.proto.nspec)), c->dt.cfg.d, c->dt.cfg.ff, es), (hipStream_t)stream);
 }
 
@@ -791,9 +823,12 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     DT_CASE(1, 2, 64, 1); DT_CASE(1, 3, 64, 1); DT_CASE(1, 4, 64, 1);
     DT_CASE(1, 2, 256, 1); DT_CASE(1, 3, 256, 1); DT_CASE(1, 4, 256, 1); DT_CASE(1, 5, 256, 1);
     DT_CASE(1, 2, 512, 1); DT_CASE(1, 3, 512, 1); DT_CASE(1, 4, 512, 2);
+    // split-fp16 (float32-equivalent) flavour: the f32 kernel's shapes
+    DT_CASE(2, 1, 64, 1); DT_CASE(2, 1, 256, 1); DT_CASE(2, 1, 512, 1); DT_CASE(2, 2, 64, 1); DT_CASE(2, 3, 64, 1); DT_CASE(2, 4, 64, 1);
+    DT_CASE(2, 2, 256, 1); DT_CASE(2, 3, 256, 1); DT_CASE(2, 2, 512, 2);
 #undef DT_CASE
     // shapes beyond the fused kernel's on-chip plan: layer-wise tiled path, same arithmetic type
-    if (prec == BUSCA_PREC_F16) {
+    if (prec == BUSCA_PREC_F16) {       // (x3 beyond the fused kernel's shapes: the exact f32 layer-wise path)
         if (d == 64) return dt_forward_tiled<1, 64>(c, K, s);
         if (d == 256) return dt_forward_tiled<1, 256>(c, K, s);
         if (d == 512) return dt_forward_tiled<1, 512>(c, K, s);

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib, weights
 
-_PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16}
+_PREC = {"f32": _lib.PREC_F32, "f16": _lib.PREC_F16, "x3": _lib.PREC_F16X3}      # x3: float32-equivalent split-fp16 GEMMs (dt_kernel.hip.inc, Prec<2>)
 _ACT = {"relu": _lib.ACT_RELU, "gelu": _lib.ACT_GELU}
 FLAVOURS = ("MEM-SEP-CAN-BAD", "MEM-SEP-CAN", "MEM-CAN-SEP-BAD", "MEM-CAN-SEP")
 

@@ -91,7 +91,9 @@ class BUSCA:
             if args.activation not in ("relu", "gelu"):
                 raise NotImplementedError("only relu/gelu are built")
             self.effective_activation = args.activation
-        self.precision = getattr(args, "precision", os.environ.get("BUSCA_AMD_PRECISION", "f32"))
+        # Decision-Transformer arithmetic: "x3" (default) = float32-EQUIVALENT GEMMs on the fp16 matrix cores (three fp16 MFMAs per product block; logits 1e-5
+        # from the exact flavour, same test bars, 2.2x its speed), "f32" = exact float32 MFMA, "f16" = fp16 operands (opt-in, ~7e-3)
+        self.precision = getattr(args, "precision", os.environ.get("BUSCA_AMD_PRECISION", "x3"))
         # ReID flavour.  "x3" (default since round 4): float32 activations, float32-equivalent products as three fp16 MFMAs - features within
         # 1e-5 of the reference's, association probabilities within 1e-3, identical decisions (tests/test_associate_gpu.py).  "f32": the same
         # parity on the exact f32 MFMA, 2x slower.  "f16": fp16 activations, 2.2-2.8x faster than x3, but it moves probabilities by up to 0.03

@@ -36,9 +36,12 @@ enum {
 
 enum { BUSCA_ACT_RELU = 0, BUSCA_ACT_GELU = 1 };
 /* arithmetic of the dense contractions; LayerNorm / softmax / residual stream are always f32.
- * BUSCA_PREC_F16X3 (ReID extractor, round 4): float32-EQUIVALENT products on the fp16 matrix cores - every f32 operand is split
- * into fp16 hi + lo and a product block is three fp16 MFMAs into one f32 accumulator (error-corrected split GEMM; measured rms
- * error 2.5e-8 of sum|a b| against float64, the f32 MFMA chain 2.8e-8); activations stay float32 in HBM, statistics float64. */
+ * BUSCA_PREC_F16X3 (ReID extractor, round 4; Decision Transformer, round 5): float32-EQUIVALENT products on the fp16 matrix cores -
+ * every f32 operand is split into fp16 hi + lo and a product block is three fp16 MFMAs into one f32 accumulator (error-corrected
+ * split GEMM; measured rms error 2.5e-8 of sum|a b| against float64, the f32 MFMA chain 2.8e-8); activations stay float32 in HBM,
+ * statistics float64.  In the Decision Transformer the GEMMs (embed, Q / K / V, out-proj, FFN) take this form, attention, LayerNorm and
+ * softmax are the f32 kernel's (logits 1e-5 from BUSCA_PREC_F32, 2.2x its speed); shapes beyond the one-kernel path run the exact f32
+ * layer-wise kernels; weights beyond |w| = 255 are refused (load them with BUSCA_PREC_F32). */
 enum { BUSCA_PREC_F32 = 0, BUSCA_PREC_F16 = 1, BUSCA_PREC_F16X3 = 2 };
 enum { BUSCA_PAIR_CENTER = 0, BUSCA_PAIR_CENTER_WEIGHTED = 1, BUSCA_PAIR_IOU = 2, BUSCA_PAIR_IOU_COST = 3 };
 
@@ -54,8 +57,8 @@ const char* busca_build_info(void);
 /* Developer options of one context (kernel-flavour selection for A/B runs and the tests that compare flavours).  Defaults are read
  * from the environment ONCE, at busca_ctx_create (BUSCA_DT_NTRK, BUSCA_DT_TILED, BUSCA_DTL_RT, BUSCA_DTL_RT_MASK);
  * no forward reads the environment.  Names: "dt_ntrk" (0 auto / 1 / 2 tracks per workgroup of the f16 fused kernel), "dt_tiled"
- * (1 = force the layer-wise path), "dtl_rt" (0 auto / 2 / 4), "dtl_rt_mask" (-1 off), "dtl_ffn" (2 = out-proj + norm1 + feed-forward + norm2 of the layer-wise path as one kernel, 1 = feed-forward block only, 0 = one kernel per GEMM; BUSCA_DTL_FFN), "dtl_attn" (1 = QKV projection + attention of a (track, head) as one kernel where built; BUSCA_DTL_ATTN), "crop_band" (1 = crops through the LDS-staged band kernel, 0 = one thread per output pixel; BUSCA_CROP_BAND); busca_get_option also
- * answers "last_dt_grid" / "last_dt_ntrk" (workgroups and tracks per workgroup of the last fused launch).  Unknown name: BUSCA_EINVAL.
+ * (1 = force the layer-wise path), "dtl_rt" (0 auto / 2 / 4), "dtl_rt_mask" (-1 off), "dtl_ffn" (2 = out-proj + norm1 + feed-forward + norm2 of the layer-wise path as one kernel, 1 = feed-forward block only, 0 = one kernel per GEMM; BUSCA_DTL_FFN), "dtl_attn" (1 = QKV projection + attention of a (track, head) as one kernel where built; BUSCA_DTL_ATTN), "crop_band" (1 = crops through the LDS-staged band kernel, 0 = one thread per output pixel; BUSCA_CROP_BAND), "dt_split" (token-split tail of the fused kernel: -1 = the tracks of a launch's last, partial round run one 16-token tile per workgroup where that pays (f32 / x3), 0 = never, 1 / 2 = every track that fits, one / two tracks per workgroup (tests); BUSCA_DT_SPLIT), "dt_prof" (debug phase stamps); busca_get_option also
+ * answers "last_dt_grid" / "last_dt_ntrk" / "last_dt_split" (workgroups, tracks per workgroup and token-split tracks of the last fused launch).  Unknown name: BUSCA_EINVAL.
  * ReID schedule knobs of a LOADED extractor (they start from the BUSCA_REID_* environment at busca_reid_load_weights and can be changed between
  * forwards): "reid_gram", "reid_halo", "reid_fuse_c1", "reid_fuse_c1_layers", "reid_fuse_c1_small", "reid_fuse_ds_layers",
  * "reid_halo_min", "reid_halo_half", "reid_halo_wpx", "reid_halo_wpx_min", "reid_gram_min", "reid_direct_rows", "reid_stats2", "reid_kwave_blocks",

@@ -26,7 +26,7 @@ def test_bench_contract_single_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and d["higher_is_better"] is True
+    assert d["dtype"] == "x3" and "float32-equivalent" in d["dtype_note"] and d["data"] == "synthetic"      # the library's default flavour and "workload" in d["config"] and d["higher_is_better"] is True
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
     assert rf["steps_per_launch"] == 20 and d["config"]["launches_in_timed_region"] == 1     # K steps = ONE 640-workgroup launch

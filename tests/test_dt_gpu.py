@@ -15,7 +15,9 @@ GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dt_*.
 
 # stated tolerances (north_star: "within a stated fp tolerance for attention scores")
 TOL = {"f32": dict(logit=2e-4, prob=2e-5, att=2e-5, hidden=5e-4, margin=1e-4),
-       "f16": dict(logit=6e-2, prob=5e-3, att=5e-3, hidden=8e-2, margin=2e-2)}
+       "f16": dict(logit=6e-2, prob=5e-3, att=5e-3, hidden=8e-2, margin=2e-2),
+       # split-fp16 GEMMs (three fp16 MFMAs per product block, 22-bit operands; attention / LayerNorm / softmax in f32): the f32 flavour's bars
+       "x3": dict(logit=2e-4, prob=2e-5, att=2e-5, hidden=5e-4, margin=1e-4)}
 
 
 @pytest.fixture(scope="module")
@@ -36,7 +38,7 @@ def _run(ctx, sd, inp, prec, fake64, **kw):
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
 @pytest.mark.parametrize("mode", ["f64", "f32"])
-@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16", "x3"])
 def test_dt_vs_reference_golden(ctx, path, mode, prec):
     g = np.load(path)
     d, ff, B, L, P, seed = (int(g[k]) for k in ("d", "ff", "B", "L", "P", "seed"))
@@ -105,7 +107,7 @@ def test_bucket_ids_equal_oracle(ctx, fake64):
     assert len(bad) == 0, "mismatching (track, token, axis): %s" % bad[:20].tolist()
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16", "x3"])
 @pytest.mark.parametrize("shape", [(32, 11, 16, 256), (32, 11, 5, 512), (5, 11, 5, 256), (1, 3, 1, 64), (7, 11, 24, 64)])
 def test_dt_vs_oracle_shapes(ctx, prec, shape):
     """Ragged / edge shapes (single track, single proposal, short memory, shipped config) vs the oracle."""
@@ -184,7 +186,7 @@ def test_two_tracks_per_workgroup_flavour(ctx, shape):
     ctx.set_option("dt_split", -1)
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16", "x3"])
 @pytest.mark.parametrize("pair", [1, 2], ids=["one-track", "two-tracks"])
 @pytest.mark.parametrize("shape", [(32, 11, 16, 256), (5, 11, 5, 256), (100, 11, 5, 512), (1, 11, 5, 512), (37, 9, 4, 64), (200, 11, 16, 256), (9, 11, 24, 64)])
 def test_token_split_tail_is_bit_identical(ctx, prec, pair, shape):
@@ -194,8 +196,8 @@ def test_token_split_tail_is_bit_identical(ctx, prec, pair, shape):
     the same order as in the one-workgroup flavour: logits, probabilities, argmax, hidden states and attention maps are bit-identical, whatever mix of
     flavours a launch uses (forced split of the last min(B, 128) tracks against no split; odd counts: the last workgroup's second track is a recomputation)."""
     B, L, P, d = shape
-    if pair == 2 and prec == "f16":
-        pytest.skip("the two-track split flavour is built for f32")
+    if pair == 2 and (prec == "f16" or L + 2 * (P + 2) <= 32):
+        pytest.skip("the two-track split flavour is built for f32 / x3 and tracks of three tiles or more")
     seed = 900 + B + d
     sd = synth.dt_state_dict(seed, d=d, ff=2 * d)
     inp = synth.dt_inputs(seed, B, L, P, sentinel_every=4)

@@ -1,11 +1,15 @@
+#!/usr/bin/env python3
+"""Token-split tail of the fused Decision-Transformer kernel, A/B in one process (option dt_split: 0 = one workgroup per track, 1 / 2 = every track split with
+one / two tracks per workgroup, -1 = the default policy): python tools/dt_split_ab.py [f32|f16] [d] [P]"""
 import numpy as np, torch, sys, os, time
 sys.path.insert(0, os.getcwd())
 from busca_amd import _lib, synth
 from busca_amd.dt import DecisionTransformerHIP
 ctx = _lib.Context(0)
-L, P, d = 11, 16, 256
+prec = sys.argv[1] if len(sys.argv) > 1 else "f32"
+L, P, d = 11, int(sys.argv[3]) if len(sys.argv) > 3 else 16, int(sys.argv[2]) if len(sys.argv) > 2 else 256
 sd = synth.dt_state_dict(3, d=d, ff=2 * d)
-m = DecisionTransformerHIP(ctx, sd, activation="relu", fake_bbox_f64=True, precision="f32")
+m = DecisionTransformerHIP(ctx, sd, activation="relu", fake_bbox_f64=True, precision=prec)
 def inputs(B):
     inp = synth.dt_inputs(3, B, L, P)
     return {k: torch.from_numpy(v).cuda() for k, v in inp.items()}

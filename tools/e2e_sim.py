@@ -10,8 +10,8 @@ from busca_amd.sim import SimScene
 from busca_amd.tracking import center_distance
 
 
-def run(lost=32, n_obj=150, P=5, d=512, precision="f32", frames=30, verbose=True, device_only_crops=False, reid_precision="x3"):
-    """Defaults = the library's defaults (busca_amd.network.BUSCA: float32 Decision Transformer + float32-equivalent x3 ReID)."""
+def run(lost=32, n_obj=150, P=5, d=512, precision="x3", frames=30, verbose=True, device_only_crops=False, reid_precision="x3"):
+    """Defaults = the library's defaults (busca_amd.network.BUSCA: float32-equivalent x3 Decision Transformer + x3 ReID)."""
     args = types.SimpleNamespace(reid_precision=reid_precision, num_layer=4, nhead=4, dim_embedding=512, trans_dim=d, ff_size=2 * d, activation="gelu", dropout_p=0.1,
                                  input_flavour="MEM-SEP-CAN-BAD", output_flavour="CAN", encode_separator_as_reference=True,
                                  encode_special_tokens=False, reid_weights_file="no", device=torch.device("cuda:0"), precision=precision, seed=7,
@@ -46,7 +46,7 @@ def run(lost=32, n_obj=150, P=5, d=512, precision="f32", frames=30, verbose=True
     return res
 
 
-def run_multi(n_seq=4, lost=8, n_obj=60, P=5, d=512, precision="f32", frames=20, reid_precision="x3"):
+def run_multi(n_seq=4, lost=8, n_obj=60, P=5, d=512, precision="x3", frames=20, reid_precision="x3"):
     """S tracker instances (sequences sharded onto this GPU) stepping in the same frame interval: S separate
     associate_embeddings calls versus the same S steps through busca_amd.batcher.StepBatcher (one Decision-Transformer launch
     per interval; every step keeps its own two ReID BatchNorm batches).  Returns per-interval p50 times and checks equality."""
