@@ -202,6 +202,7 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
     if (n == "dt_ntrk") *value = o.dt_ntrk;
     else if (n == "dt_split") *value = o.dt_split;
     else if (n == "last_dt_split") *value = o.last_dt_split;
+    else if (n == "dt_status") *value = c->dt.xerr ? *c->dt.xerr : 0;       // 0 ok, 1 a split launch lost a partner, 2 an x3 forward clipped an operand (also reported by the next forward)
     else if (n == "dt_tiled") *value = o.dt_tiled;
     else if (n == "dtl_rt") *value = o.dtl_rt;
     else if (n == "dtl_rt_mask") *value = o.dtl_rt_mask;
@@ -362,14 +363,13 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
     const float* cur = blob;
     auto take = [&](size_t n) { const float* p = cur; cur += n; return p; };
     auto put_vec = [&](const float* src, size_t n) { size_t off = reserve(n * 4); memcpy(host.data() + off, src, n * 4); return off; };
-    if (prec == BUSCA_PREC_F16X3) {
-        // the split-fp16 flavour carries weights as DT_X3_WS * w in fp16 hi + lo: a checkpoint beyond that range must not be clipped silently
-        float wmax = 0.f;
-        for (size_t i = 0; i < blob_floats; ++i) wmax = std::max(wmax, std::fabs(blob[i]));
-        if (!(wmax * DT_X3_WS <= 65504.f))
-            return fail(c, BUSCA_EINVAL, "Decision-Transformer weights reach |w| = %g, beyond the split-fp16 (BUSCA_PREC_F16X3) operand range of %g: load them with BUSCA_PREC_F32", (double)wmax, 65504.0 / DT_X3_WS);
-    }
-    auto put_mat = [&](const float* src, int N, int K) { size_t off = reserve((size_t)N * K * es); pack_matrix(src, N, K, prec, host.data() + off); return off; };
+    float wmax = 0.f;          // largest matrix entry (x3: the split-fp16 flavour carries DT_X3_WS * w in fp16 hi + lo - a checkpoint beyond that range must not be clipped silently)
+    auto put_mat = [&](const float* src, int N, int K) {
+        size_t off = reserve((size_t)N * K * es);
+        for (size_t i = 0; i < (size_t)N * K; ++i) wmax = std::max(wmax, std::fabs(src[i]));
+        pack_matrix(src, N, K, prec, host.data() + off);
+        return off;
+    };
 
     struct Offs { size_t w_in, b_in, w_out, b_out, w1, b1, w2, b2, g1, be1, g2, be2; } lo[DT_MAX_LAYERS];
     const size_t o_wemb = put_mat(take((size_t)d * E), d, E);
@@ -392,6 +392,8 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
     auto put_lut = [&](const uint16_t* src, size_t rows) { size_t off = reserve(rows * lut_c * 2); memcpy(host.data() + off, src, rows * lut_c * 2); return off; };
     const size_t o_lxy = put_lut(lut_xy, 211), o_lsz = put_lut(lut_sz, 211), o_lt = put_lut(lut_t, 61);
 
+    if (prec == BUSCA_PREC_F16X3 && !(wmax * DT_X3_WS <= 65504.f))
+        return fail(c, BUSCA_EINVAL, "Decision-Transformer weights reach |w| = %g, beyond the split-fp16 (BUSCA_PREC_F16X3) operand range of %g: load them with BUSCA_PREC_F32", (double)wmax, 65504.0 / DT_X3_WS);
     DTState& S = c->dt;
     if (S.dev_blob) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, hipFree(S.dev_blob)); S.dev_blob = nullptr; S.loaded = false; }
     HIP_TRY(c, hipMalloc(&S.dev_blob, host.size()));
@@ -479,7 +481,7 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
 // (a one-tile workgroup is bound by its weight stream through the CU's vector memory path: two to a CU take twice as long); beyond that two tracks
 // share a workgroup, every streamed weight fragment feeding two tiles (f32 flavour, tracks of three tiles or more - with two tiles such a workgroup
 // would do a whole track's work).  A partial round too large for either stays one workgroup per track.
-static int dt_split_tracks(const busca_ctx* c, int B, int parts, bool by_default, bool can_pair, int* pair) {
+static int dt_split_tracks(const busca_ctx* c, int B, int parts, int prec, bool can_pair, int* pair) {
     const DTState& S = c->dt;
     *pair = 1;
     if (S.xslots <= 0 || c->opt.dt_split == 0 || parts > DT_XMAX_MT) return 0;
@@ -489,9 +491,13 @@ static int dt_split_tracks(const busca_ctx* c, int B, int parts, bool by_default
     }
     // (f16 is left alone: that kernel is bound by the weight stream, which every workgroup of a split track repeats - measured 0.083 vs 0.085 ms for a
     // 32-track step, slower from one pass of workgroups on)
-    if (!by_default) return 0;
+    if (prec == BUSCA_PREC_F16) return 0;
     const int rem = B % S.num_cu;
     if (rem == 0 || rem + 1 > S.xslots) return 0;
+    // x3 is bound by the weight stream (L1 / L2), not by the MFMA: a partial round already runs faster than a full one (640 tracks 0.607 ms against
+    // 3 x 0.225) and split workgroups add weight traffic - they pay only while the launch is small (32-track step 0.183 -> 0.134 ms; 128 tracks of two
+    // tiles at d = 512: 0.407 -> 0.430)
+    if (prec == BUSCA_PREC_F16X3) return 2 * parts * rem <= S.num_cu ? rem : 0;
     if (parts * rem <= S.num_cu) return rem;
     if (can_pair && parts * ((rem + 1) / 2) <= S.num_cu) { *pair = 2; return rem; }
     return 0;
@@ -516,7 +522,6 @@ template <int PREC, int MT, int D, int FF, int NCH, int NTRK>
 static int dt_launch_split(busca_ctx* c, const DTParams& P0, int nsplit, hipStream_t s) {
     typedef DTLds<PREC, 1, D, FF, 512, NCH, NTRK> LD;
     DTState& S = c->dt;
-    if (*S.xerr) return fail(c, BUSCA_EHIP, "a token-split Decision-Transformer launch gave up waiting for a partner workgroup: its results were invalid");
     auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH, NTRK, true>;
     const int nwg = ((nsplit + NTRK - 1) / NTRK) * MT;
     DTParams P = P0;
@@ -550,7 +555,7 @@ static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
         { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
         // whole rounds of one-track workgroups, then the tail's tracks one token tile per workgroup: ONE timed region (the step batch), two launches on the stream
         int pair = 1;
-        const int nsplit = c->opt.dt_prof == 1 ? 0 : dt_split_tracks(c, P.B, MT, PREC != 1, PAIR, &pair);
+        const int nsplit = c->opt.dt_prof == 1 ? 0 : dt_split_tracks(c, P.B, MT, PREC, PAIR, &pair);
         if (nsplit > 0) {
             c->opt.last_dt_grid = P.B - nsplit + ((nsplit + pair - 1) / pair) * MT; c->opt.last_dt_split = nsplit; c->opt.last_dt_ntrk = pair;
             TimedLaunch tl(c, s);
@@ -799,6 +804,14 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     K.mem_feat = mem_feat; K.can_feat = can_feat; K.mem_ltrb = mem_ltrb; K.can_ltrb = can_ltrb;
     K.logits = logits; K.probs = probs; K.argmax = argmax; K.hidden = hidden; K.att = att;
     K.B = B; K.L = L; K.P = P; K.T = L + 2 * (P + K.nspec);
+    if (c->dt.xerr && *c->dt.xerr) {         // written by a kernel of an EARLIER call (host-mapped memory): reported once, then cleared
+        const int st = *c->dt.xerr;
+        *c->dt.xerr = 0;
+        if (st == 2) return fail(c, BUSCA_EINVAL, "an earlier Decision-Transformer forward clipped activations beyond the split-fp16 (BUSCA_PREC_F16X3) operand range "
+                                                  "(|x| > 1023.5): its results were not float32-equivalent; load this model with BUSCA_PREC_F32");
+        return fail(c, BUSCA_EHIP, "an earlier token-split Decision-Transformer launch gave up waiting for a partner workgroup: its results were invalid");
+    }
+    K.xerr = c->dt.xerr_dev;
     const int MT = (K.T + 15) / 16;
     const int d = c->dt.cfg.d, prec = c->dt.cfg.precision;
     hipStream_t s = (hipStream_t)stream;

@@ -221,6 +221,35 @@ def test_token_split_tail_is_bit_identical(ctx, prec, pair, shape):
         assert np.array_equal(one[k], two[k]), k
 
 
+def test_x3_reports_operands_beyond_its_range(ctx):
+    """The split-fp16 flavour carries activations as fp16 hi + lo of 64 x: |x| > 1023.5 cannot be represented.  Such a forward is not clipped silently -
+    the kernel raises a status word in host-mapped memory (`dt_status` 2) and the next forward of the context fails with the reason; weights beyond
+    |w| = 255 are refused when they are loaded.  The exact f32 flavour takes both."""
+    from busca_amd import _lib
+    from busca_amd.dt import DecisionTransformerHIP
+    sd = synth.dt_state_dict(11, d=256, ff=512)
+    inp = synth.dt_inputs(11, 8, 11, 16)
+    out, m = _run(ctx, sd, inp, "x3", True)
+    assert ctx.get_option("dt_status") == 0
+    hot = dict(sd)
+    hot["transformer_encoder.layers.1.norm1.weight"] = sd["transformer_encoder.layers.1.norm1.weight"] * 3000.0     # LayerNorm outputs of ~ +-9000
+    _run(ctx, hot, inp, "f32", True)                    # fine in exact f32
+    assert ctx.get_option("dt_status") == 0
+    _, mh = _run(ctx, hot, inp, "x3", True)             # (_run synchronises)
+    assert ctx.get_option("dt_status") == 2
+    with pytest.raises(_lib.BuscaError, match="split-fp16"):
+        mh.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])
+    assert ctx.get_option("dt_status") == 0             # reported once
+    again = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])
+    torch.cuda.synchronize()
+    assert np.array_equal(again["logits"].cpu().numpy(), out["logits"]) and ctx.get_option("dt_status") == 0
+    big = dict(sd)
+    big["transformer_encoder.layers.0.linear1.weight"] = sd["transformer_encoder.layers.0.linear1.weight"] * 1.0e4
+    with pytest.raises(_lib.BuscaError, match="split-fp16"):
+        DecisionTransformerHIP(ctx, big, activation="relu", precision="x3")
+    DecisionTransformerHIP(ctx, big, activation="relu", precision="f32")
+
+
 def test_token_split_tail_policy(ctx):
     """Which launches take the split tail by default (256 CUs, 47 tokens = three tiles): the tracks of the last, partial round - one track per workgroup
     while three workgroups per track fit one pass over the CUs (85 tracks), two tracks per workgroup while those fit (170 tracks), else no split."""

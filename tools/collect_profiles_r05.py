@@ -11,6 +11,10 @@ ent = d.setdefault("reid_x3_n512", {})
 ent.update({"correction": "read = FETCH_SIZE KiB x 2 (gfx950 wide-read undercount, MI355X_MICROARCH.md HBM section); write = WRITE_SIZE KiB as reported",
             "source": "tools/pmc_traffic.sh (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, --kernel-trace only), python3 tools/reid_bench.py 512 2 x3; profiles/r05_reid_x3_512_pmc_traffic.txt",
             "round": 5, "hbm_bytes_per_pass": (float(tot[3]) + float(tot[4])) * 1e6, "read_bytes": float(tot[3]) * 1e6, "write_bytes": float(tot[4]) * 1e6, "kernel_us_per_pass": float(tot[2])})
+if os.path.exists(P + "pmc_dt/entries.json"):       # Decision-Transformer launch shapes (tools/pmc_dt_traffic.sh): this round's measurement replaces the entry
+    for k, v in json.load(open(P + "pmc_dt/entries.json")).items():
+        v["round"] = 5
+        d[k] = v
 json.dump(d, open("profiles/pmc_traffic.json", "w"), indent=1)
 cp = {"bench_steps20.json": "r05_bench_steps20.json", "bench_default.json": "r05_bench_default.json",
       "reid_x3_512_timeline.txt": "r05_reid_x3_512_timeline.txt", "reid_x3_352_timeline.txt": "r05_reid_x3_352_timeline.txt",
@@ -19,7 +23,8 @@ cp = {"bench_steps20.json": "r05_bench_steps20.json", "bench_default.json": "r05
       "dt_f32_steps20.stats.txt": "r05_dt_f32_steps20_kernel_stats.txt", "dtl_cfg5_f16.stats.txt": "r05_dtl_cfg5_f16_kernel_stats.txt", "dtl_cfg4_f32.stats.txt": "r05_dtl_cfg4_f32_kernel_stats.txt",
       "hbm_kernels.stats.txt": "r05_hbm_kernels_kernel_stats.txt", "hbm_kernels_pmc_traffic.txt": "r05_hbm_kernels_pmc_traffic.txt", "hbm_kernels.log": "r05_hbm_kernels_table.json",
       "reid_x3_512_sq_counters.txt": "r05_reid_x3_512_sq_counters.txt", "reid_x3_512_pmc_traffic.txt": "r05_reid_x3_512_pmc_traffic.txt",
-      "dt_f32_steps20/t_kernel_stats.csv": "r05_dt_f32_steps20_rocprof_kernel_stats.csv"}
+      "dt_f32_steps20/t_kernel_stats.csv": "r05_dt_f32_steps20_rocprof_kernel_stats.csv",
+      "dt_x3_steps20.stats.txt": "r05_dt_x3_steps20_kernel_stats.txt", "dt_x3_steps20/t_kernel_stats.csv": "r05_dt_x3_steps20_rocprof_kernel_stats.csv"}
 for a, b in cp.items():
     if os.path.exists(P + a):
         shutil.copy(P + a, "profiles/" + b)

@@ -13,6 +13,10 @@ while read KEY BT P D PREC; do
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/$KEY -o write -- python3 tools/dt_cfg_bench.py $BT $P $D $PREC 4 > $OUT/$KEY.write.log 2>&1
   tail -1 $OUT/$KEY.write.log
 done <<LIST
+dt_x3_F20_B32_P16_d256 640 16 256 x3
+dt_x3_F64_B32_P16_d256 2048 16 256 x3
+dt_x3_F8_B32_P16_d256 256 16 256 x3
+dt_x3_F8_B32_P5_d512 256 5 512 x3
 dt_f32_F20_B32_P16_d256 640 16 256 f32
 dt_f32_F64_B32_P16_d256 2048 16 256 f32
 dt_f32_F8_B32_P16_d256 256 16 256 f32
