@@ -46,7 +46,7 @@ struct DTState {
     void* dev_tiled = nullptr;     // row-major f16 matrices (tiled path)
     DTTiledW tw;
     void* ws = nullptr; size_t ws_bytes = 0;   // tiled-path activation workspace
-    // token-split tail of the fused kernel (dt_fused_mixed_kernel): K / V exchange tiles, flags, decoder hand-over of up to xslots tracks; xepoch
+    // token-split tail of the fused kernel (dt_fused_kernel<..., SPLIT = true>): K / V exchange tiles, flags, decoder hand-over of up to xslots tracks; xepoch
     // numbers the launches (flags only ever grow, nothing is cleared between launches); xerr is host memory the kernel writes if a wait ran out
     void* xch = nullptr; unsigned* xflag = nullptr; float* xlg = nullptr; int* xerr = nullptr; int* xerr_dev = nullptr; int xslots = 0; unsigned xepoch = 0;
     int num_cu = 256;
