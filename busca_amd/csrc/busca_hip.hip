@@ -43,6 +43,8 @@ struct DTState {
     void* dev_blob = nullptr;      // one allocation holding every packed matrix / vector / LUT
     size_t dev_bytes = 0;
     DTParams proto{};              // weight pointers filled in, per-call fields zero
+    void* dev_blob32 = nullptr;    // x3 only: the matrices once more, packed for the exact f32 kernels (the layer-wise path of shapes beyond the one-kernel path)
+    DTParams proto32{};            // = proto with the matrix pointers into dev_blob32
     void* dev_tiled = nullptr;     // row-major f16 matrices (tiled path)
     DTTiledW tw;
     void* ws = nullptr; size_t ws_bytes = 0;   // tiled-path activation workspace
@@ -237,6 +239,7 @@ extern "C" void busca_ctx_destroy(busca_ctx* c) {
     if (c->dt.dev_blob) hipFree(c->dt.dev_blob);
     if (c->dt.dev_tiled) hipFree(c->dt.dev_tiled);
     if (c->dt.ws) hipFree(c->dt.ws);
+    if (c->dt.dev_blob32) hipFree(c->dt.dev_blob32);
     if (c->dt.xch) hipFree(c->dt.xch);
     if (c->dt.xflag) hipFree(c->dt.xflag);
     if (c->dt.xlg) hipFree(c->dt.xlg);
@@ -421,6 +424,30 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
     P.sep_can = (g->layout & BUSCA_LAYOUT_SEP_AS_CAN) ? 1 : 0;
     if (P.nspec == 1) P.fake_f64 = 0;    // the float64 promotion comes from torch.cat with the float64 BAD box (encodings.py:127-140): no BAD, no promotion
     S.proto = P;
+    S.proto32 = P;
+    if (S.dev_blob32) { HIP_TRY(c, hipFree(S.dev_blob32)); S.dev_blob32 = nullptr; }
+    if (prec == BUSCA_PREC_F16X3) {
+        // the layer-wise kernels that take fragment-packed weights (dtl_qkv_attn_kernel, dtl_ffn_kernel) run in exact f32 for this flavour: a second packing
+        std::vector<unsigned char> h32;
+        auto put32 = [&](const float* src, int N, int K) { size_t off = (h32.size() + 255) & ~(size_t)255; h32.resize(off + (size_t)N * K * 4); pack_matrix(src, N, K, BUSCA_PREC_F32, h32.data() + off); return off; };
+        const float* q = blob;
+        const size_t e32 = put32(q, d, E); q += (size_t)d * E + d + 3 * d;
+        size_t oi[DT_MAX_LAYERS], oo[DT_MAX_LAYERS], o1[DT_MAX_LAYERS], o2[DT_MAX_LAYERS];
+        for (int l = 0; l < g->nlayers; ++l) {
+            oi[l] = put32(q, 3 * d, d); q += (size_t)3 * d * d + 3 * d;
+            oo[l] = put32(q, d, d); q += (size_t)d * d + d;
+            o1[l] = put32(q, ff, d); q += (size_t)ff * d + ff;
+            o2[l] = put32(q, d, ff); q += (size_t)d * ff + d + 4 * d;
+        }
+        HIP_TRY(c, hipMalloc(&S.dev_blob32, h32.size()));
+        HIP_TRY(c, hipMemcpy(S.dev_blob32, h32.data(), h32.size(), hipMemcpyHostToDevice));
+        const char* b32 = (const char*)S.dev_blob32;
+        S.proto32.w_embed = (const u32x4*)(b32 + e32);
+        for (int l = 0; l < g->nlayers; ++l) {
+            DTLayerW& W = S.proto32.layer[l];
+            W.w_in = (const u32x4*)(b32 + oi[l]); W.w_out = (const u32x4*)(b32 + oo[l]); W.w1 = (const u32x4*)(b32 + o1[l]); W.w2 = (const u32x4*)(b32 + o2[l]);
+        }
+    }
     S.cfg = *g;
     if (S.dev_tiled) { HIP_TRY(c, hipFree(S.dev_tiled)); S.dev_tiled = nullptr; }
     S.tw = DTTiledW();
@@ -846,6 +873,10 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
         if (d == 256) return dt_forward_tiled<1, 256>(c, K, s);
         if (d == 512) return dt_forward_tiled<1, 512>(c, K, s);
     } else {
+        if (prec == BUSCA_PREC_F16X3) {      // the f32 packing of the matrices (proto32)
+            K.w_embed = c->dt.proto32.w_embed;
+            for (int l = 0; l < K.nlayers; ++l) { K.layer[l].w_in = c->dt.proto32.layer[l].w_in; K.layer[l].w_out = c->dt.proto32.layer[l].w_out; K.layer[l].w1 = c->dt.proto32.layer[l].w1; K.layer[l].w2 = c->dt.proto32.layer[l].w2; }
+        }
         if (d == 64) return dt_forward_tiled<0, 64>(c, K, s);
         if (d == 256) return dt_forward_tiled<0, 256>(c, K, s);
         if (d == 512) return dt_forward_tiled<0, 512>(c, K, s);

@@ -136,13 +136,15 @@ def test_device_resident_track_memory(model, host_copy):
     assert np.array_equal(a, b) and np.array_equal(ra, rb)
 
 
-@pytest.mark.parametrize("reid_prec", ["f32", "x3"])
+@pytest.mark.parametrize("reid_prec", ["f32", "x3", "x3+x3"])
 @pytest.mark.parametrize("ci", [0, 1, 2, 3])
 def test_associate_exact_flavours_vs_reference(golden_dir, ci, reid_prec):
-    """f32 Decision Transformer + a float32-class ReID ("f32": exact f32 MFMA; "x3": split-fp16 products, BUSCA_PREC_F16X3): the
-    whole associate_embeddings output agrees with the reference's to float32 round-off, and the one-hot decisions are identical."""
+    """f32 Decision Transformer + a float32-class ReID ("f32": exact f32 MFMA; "x3": split-fp16 products, BUSCA_PREC_F16X3; "x3+x3": the library's
+    default, split-fp16 products in the Decision Transformer too): the whole associate_embeddings output agrees with the reference's to float32
+    round-off, and the one-hot decisions are identical."""
     from busca_amd.network import BUSCA
-    a = _args(precision="f32")
+    a = _args(precision="x3" if reid_prec == "x3+x3" else "f32")
+    reid_prec = reid_prec.split("+")[0]
     a.reid_precision = reid_prec
     m = BUSCA(a).to(torch.device("cuda:0")).eval()
     sd = dict(synth.dt_state_dict(17, d=64, ff=128))
@@ -396,7 +398,7 @@ def test_associate_selection_thresholds_vs_reference(golden_dir):
             assert np.abs(pm - ref).max() <= 2e-4, (name, si, np.abs(pm - ref).max())
 
 
-@pytest.mark.parametrize("flavour", ["exact", "x3", "fast"])
+@pytest.mark.parametrize("flavour", ["exact", "x3", "default", "fast"])
 def test_associate_shipped_shape_vs_reference(golden_dir, flavour):
     """cfgR - the shape every shipped config runs (d=512, ff=1024, L=11, P=5, Kalman candidates, broader memory) - end to end
     against the reference's associate_embeddings (tests/golden/assoc512.npz): exact flavours to float32 round-off with
@@ -405,8 +407,15 @@ def test_associate_shipped_shape_vs_reference(golden_dir, flavour):
     g = np.load(os.path.join(golden_dir, "assoc512.npz"))
     name, hist, n_det, kal, P = mg.ASSOC512_CASE
     tracks, dets, kals = mg.assoc_scene(23, hist, n_det, kal)
-    # "x3": float32 DT + the float32-equivalent split-fp16 ReID - held to the exact flavour's bar
-    m = _model(512, 1024, 23, "f32", "f32") if flavour == "exact" else _model(512, 1024, 23, "f32", "x3") if flavour == "x3" else _model(512, 1024, 23, "f16", "f16")
+    # "x3": float32 DT + the float32-equivalent split-fp16 ReID; "default" (round 5): split-fp16 in the Decision Transformer too - both held to the exact flavour's bar
+    m = {"exact": lambda: _model(512, 1024, 23, "f32", "f32"), "x3": lambda: _model(512, 1024, 23, "f32", "x3"), "default": lambda: _model(512, 1024, 23, "x3", "x3"),
+         "fast": lambda: _model(512, 1024, 23, "f16", "f16")}[flavour]()
+    if flavour == "default":
+        from busca_amd.network import BUSCA
+        import types
+        assert m.precision == "x3" and m.reid_precision == "x3"
+        dflt = BUSCA(types.SimpleNamespace(**{k: v for k, v in vars(_args(512, 1024)).items() if k != "precision"}))
+        assert dflt.precision == "x3" and dflt.reid_precision == "x3"         # what a caller who sets nothing gets
     tol = 6e-2 if flavour == "fast" else 1e-3          # d=512 amplifies feature round-off ~10x (see test_oracle_golden.py)
     for mode in ("f64", "f32"):
         m.pinned_numpy = (mode == "f64")

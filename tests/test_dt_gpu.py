@@ -271,7 +271,7 @@ def _flavour_file():
 
 
 @pytest.mark.parametrize("mode", ["f64", "f32"])
-@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16", "x3"])
 @pytest.mark.parametrize("tiled", [0, 1], ids=["fused", "layerwise"])
 def test_token_layout_flavours_vs_reference(ctx, mode, prec, tiled):
     """MEM-SEP-CAN / MEM-CAN-SEP, with and without the BAD token, separators encoded as the reference box or as their candidate's:
@@ -342,7 +342,7 @@ def test_busca_accepts_the_reference_flavour_options():
     BUSCA(args(encode_special_tokens=True, trans_dim=512, ff_size=1024))   # same widths: the option changes nothing
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16", "x3"])      # (x3 outside the one-kernel geometry = the exact f32 layer-wise kernels)
 def test_other_head_counts_and_ff_widths_vs_reference(ctx, prec):
     """nhead / ff_size other than the shipped 4 / 2 d run layer-wise (head widths 16 / 32 / 64 / 128, ff = k d): against outputs
     of the reference itself (tests/golden/make_golden.py dt_geometry)."""

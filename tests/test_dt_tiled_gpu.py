@@ -86,6 +86,25 @@ def test_tiled_large_shapes_vs_oracle(ctx, shape, prec):
     assert (out["argmax"][clear] == ref["argmax"].numpy()[clear]).all()
 
 
+@pytest.mark.parametrize("shape", [(16, 11, 32, 512), (6, 11, 40, 256)], ids=lambda s: "B%d_L%d_P%d_d%d" % s)
+def test_x3_beyond_the_one_kernel_shapes_is_the_exact_f32_path(ctx, shape):
+    """The split-fp16 flavour (the default) is built for the one-kernel path; a shape beyond it runs the exact f32 layer-wise kernels on an f32 packing of
+    the same weights: outputs bit-identical to the f32 flavour's (round 5: the x3-packed weights must never reach an f32 kernel)."""
+    from busca_amd.dt import DecisionTransformerHIP
+    B, L, P, d = shape
+    sd = synth.dt_state_dict(70 + d, d=d, ff=2 * d)
+    inp = synth.dt_inputs(70 + d, B, L, P, sentinel_every=4)
+    outs = {}
+    for prec in ("f32", "x3"):
+        m = DecisionTransformerHIP(ctx, sd, activation="relu", precision=prec)
+        o = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"], want_hidden=True)
+        torch.cuda.synchronize()
+        outs[prec] = {k: v.cpu().numpy() for k, v in o.items()}
+    for k in ("logits", "probs", "argmax", "hidden"):
+        assert np.array_equal(outs["f32"][k], outs["x3"][k]), k
+    assert np.abs(outs["x3"]["logits"]).max() > 0 and np.ptp(outs["x3"]["logits"]) > 1e-3
+
+
 def test_unsupported_shape_is_refused_loudly(ctx):
     """More than 144 tokens per track is beyond every path: a BuscaError, never a silent fallback."""
     from busca_amd import _lib
