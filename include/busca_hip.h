@@ -116,6 +116,10 @@ int busca_dt_load_weights(busca_ctx* ctx, const busca_dt_cfg* cfg, const float* 
  *   argmax   [B]     i32  first index of the row maximum of probs              (may be NULL)
  *   hidden   [B,T,d] f32  transformer output (source of .logits/.mem_logits)   (may be NULL)
  *   att      [nlayers,B,nhead,T,T] f32 per-head attention weights              (may be NULL)
+ * One Decision-Transformer forward per context at a time (its layer-wise workspace and the exchange buffers of the token-split tail belong
+ * to the context; forwards on ONE stream are ordered by the stream - use one context per concurrently running stream).  A forward of the
+ * BUSCA_PREC_F16X3 flavour that had to clip an operand, or a split launch that lost a partner workgroup, is reported by the NEXT call
+ * (BUSCA_EINVAL / BUSCA_EHIP with the reason) and by busca_get_option("dt_status").
  */
 int busca_dt_forward(busca_ctx* ctx, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
                      const float* can_ltrb, int32_t B, int32_t L, int32_t P, float* logits, float* probs,
