@@ -250,6 +250,15 @@ def test_x3_reports_operands_beyond_its_range(ctx):
     DecisionTransformerHIP(ctx, big, activation="relu", precision="f32")
 
 
+def test_token_split_exchange_under_back_to_back_launches():
+    """tools/dt_split_stress.py: hundreds of back-to-back forwards of changing track counts, widths and flavours (f32 / x3) on ONE context, forced and default split
+    (the exchange buffers, layer-parity slots and only-growing flags are reused at once), every output bit-identical to the unsplit flavour and `dt_status` 0."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dt_split_stress.py"), "150"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+
+
 def test_token_split_tail_policy(ctx):
     """Which launches take the split tail by default (256 CUs, 47 tokens = three tiles): the tracks of the last, partial round - one track per workgroup
     while three workgroups per track fit one pass over the CUs (85 tracks), two tracks per workgroup while those fit (170 tracks), else no split."""
