@@ -13,8 +13,11 @@ one call, i.e. one launch processes F steps and fills the 256 CUs; the single-fr
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  Primary line = exact-f32 MFMA arithmetic (the reference computes in fp32); the
-f16-operand flavour is reported under `variants`.
+Rank 0 prints ONE short JSON line on stdout (the contract keys + `roofline` + `cpu_baseline` + `variants` reduced to
+{value, dtype, frac}; at most MAX_LINE characters - the driver keeps only a few KB of stdout) and writes everything it measured
+(the per-config legs, full steps, end-to-end latencies, HBM-kernel table, per-rank reports, notes) to `bench_detail.json` next to
+this file.  Primary line = exact-f32 MFMA arithmetic (the reference computes in float32, busca/custom_layers.py:30-41); the
+library's default x3 flavour and the opt-in f16 flavour are reported under `variants`.
 """
 import argparse
 import ctypes as C
@@ -178,8 +181,7 @@ def roofline_obj(precision, B, L, P, d, ff, timing, bracket_ms_per_call, kernel=
         traffic, traffic_note = None, "profiles/pmc_traffic.json unreadable: %r" % (e,)
     if geometry and geometry.get("token_split_tracks"):
         kernel += " (two launches in one bracketed region: <SPLIT=false> for the whole rounds of one-track workgroups + <SPLIT=true> for the %d tracks of the last round, one token tile per workgroup)" % geometry["token_split_tracks"]
-    extra = {"frac_of_f32_mfma_peak": ach / PEAK_TFLOPS["f32"],
-             "peak_note": "x3 = float32-equivalent GEMMs as three fp16 MFMAs per product block: peak = the dense fp16 MFMA peak / 3 (the 4 % of the FLOPs in the attention run on the f32 MFMA)"} if precision == "x3" else {}
+    extra = {"peak_note": "x3 = float32-equivalent GEMMs as three fp16 MFMAs per product block: peak = the dense fp16 MFMA peak / 3 (the 4 % of the FLOPs in the attention run on the f32 MFMA)"} if precision == "x3" else {}
     return {**extra, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[precision], "launch_geometry": geometry,
             "traffic": traffic, "traffic_note": traffic_note, "kernel": kernel, "kernel_avg_ms": tot_ms / max(1, nk), "kernel_launches_per_call": nk / max(1, calls),
             "kernel_ms_per_call": tot_ms / max(1, calls), "flops_per_call": flops / max(1, calls),
@@ -266,7 +268,7 @@ def full_step(ctx, dt_model, B, L, P, n_steps, dev, n_det=None, reid_precision="
         traffic = None
     peak = PEAK_TFLOPS[reid_precision]
     arith = {"f16": "fp16", "f32": "float32", "x3": "float32 split into fp16 hi + lo, three fp16 MFMAs per product block (float32-equivalent)"}[reid_precision]
-    extra = {"frac_of_f32_mfma_peak": tf / PEAK_TFLOPS["f32"], "peak_note": "peak = fp16 MFMA peak / 3 (three MFMAs per float32-equivalent product)"} if reid_precision == "x3" else {}
+    extra = {"peak_note": "peak = fp16 MFMA peak / 3 (three MFMAs per float32-equivalent product)"} if reid_precision == "x3" else {}
     return {"value": 1.0 / dt, "unit": "steps/s", "ms_per_step": dt * 1e3, "crop_slots_per_step": slots, "crops_per_step": crops,
             "candidate_crops": "all distinct" if n_det is None else "%d slots drawn from %d detections (repeats computed once, weighted statistics)" % (B * P, n_det),
             "reid_algorithmic_tflop_per_step": crops * REID_GFLOP_PER_CROP / 1e3,
@@ -316,7 +318,7 @@ def assoc_e2e(frames):
         out["multi_sequence_4x_lost8"] = {"error": repr(e)}
     out["config"] = ("shipped model shape d=512 ff=1024 L=11 P=5, random weights, synthetic 1080p frames; p50_crop_ms = the frame's two get_image_crops calls "
                      "(detections + Kalman boxes: ONE frame upload inside an explicit model.frame(img) scope, crop kernel, lazy host copy enqueued) until the tracker's stream is done; "
-                     "UNPREFIXED keys = library defaults: float32 DT + float32-equivalent x3 ReID (split-fp16 MFMA); f16_* keys: opt-in f16 MFMA DT + fp16 ReID; "
+                     "UNPREFIXED keys = library defaults: float32-equivalent x3 DT + float32-equivalent x3 ReID (both split-fp16 MFMA); f16_* keys: opt-in f16 MFMA DT + fp16 ReID; "
                      "f32_* keys: float32 DT + exact-f32 ReID (reference arithmetic)")
     return out
 
@@ -353,7 +355,7 @@ def hbm_kernels(ctx, dev):
     tlbr = np.stack([x, y, x + ww, y + hh], 1)
     ext = np.stack([np.floor(tlbr[:, 0]), np.floor(tlbr[:, 1]), np.ceil(tlbr[:, 2]), np.ceil(tlbr[:, 3])], 1)
     src_bytes = float(((ext[:, 2] - ext[:, 0]) * (ext[:, 3] - ext[:, 1]) * 3).sum())
-    out["crop_gather_150_boxes_1080p"] = entry("crop_fill_kernel + crop_resize_kernel", "150 boxes of a 1080p frame -> u8 [150,384,128,3]",
+    out["crop_gather_150_boxes_1080p"] = entry("crop_band_kernel", "150 boxes of a 1080p frame -> u8 [150,384,128,3]",
                                                src_bytes + 150 * 147456, timed(lambda: geometry.crop_gather(ctx, frame, tlbr, want_u8=True)))
     # track-memory gather: 864 crops (32 lost x (11 memory + 16 candidate) slots) out of a resident batch
     res = torch.from_numpy(synth.randint_u8(6, "res", (256, 384, 128, 3))).to(dev)
@@ -423,6 +425,71 @@ def cfg5_split_leg(ctx, dev, rank, world, dist, red_dev, steps, seed=7):
                          "note": "whole-step wall time incl. host gather; peak = %d x the per-GPU f16 MFMA peak" % world}}
 
 
+MAX_LINE = 6000          # the driver keeps about 8 KB of stdout: the contract line stays well inside that
+
+
+def _short(x, sig=6):
+    """Floats to `sig` significant digits, recursively (the full-precision numbers are in bench_detail.json)."""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _short(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_short(v, sig) for v in x]
+    return x
+
+
+def contract_line(res, detail_path):
+    """The ONE stdout line: the contract keys, `roofline`, `cpu_baseline`, and {value, dtype, frac} per variant / config leg."""
+    out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                               "dtype", "data", "p50_latency_ms") if k in res}
+    out["config"] = res["config"]
+    rf = res["roofline"]
+    out["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_avg_ms", "kernel_launches_per_call",
+                                          "kernel_ms_per_call", "steps_per_launch", "algorithmic_bytes_per_step", "flops_per_call") if k in rf}
+    out["cpu_baseline"] = res.get("cpu_baseline")
+
+    def brief(v):
+        if not isinstance(v, dict) or "error" in v or "value" not in v:
+            return {"error": str(v.get("error", "no value"))[:80]} if isinstance(v, dict) else None
+        b = {"value": v["value"], "dtype": v.get("dtype"), "frac": (v.get("roofline") or {}).get("frac")}
+        if v.get("n_gpus", 1) != 1:
+            b["n_gpus"] = v["n_gpus"]
+        return b
+
+    if res.get("variants"):
+        out["variants"] = {k: brief(v) for k, v in res["variants"].items()}
+    if res.get("configs"):
+        out["configs"] = {k: brief(v) for k, v in res["configs"].items()}
+    for k in ("full_step", "full_step_f32"):
+        if isinstance(res.get(k), dict) and "value" in res[k]:
+            out.setdefault("configs", {})[k] = brief(res[k])
+    if detail_path:
+        out["detail"] = os.path.basename(detail_path)
+    out = _short(out)
+    line = json.dumps(out, separators=(",", ":"))
+    for drop in ("configs", "variants", "p50_latency_ms"):         # never reached with today's legs; the line must parse whatever is added later
+        if len(line) <= MAX_LINE:
+            break
+        out.pop(drop, None)
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) > MAX_LINE:
+        raise RuntimeError("bench.py: contract line is %d characters (> %d)" % (len(line), MAX_LINE))
+    return line
+
+
+def emit(result, detail_path, out=None):
+    if detail_path:
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(result, f, indent=1)
+                f.write("\n")
+        except OSError as e:
+            print("bench.py: could not write %s: %r" % (detail_path, e), file=sys.stderr)
+            detail_path = None
+    print(contract_line(result, detail_path), file=out or sys.stdout, flush=True)
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (python -m torch.distributed.run), relay
     rank 0's JSON line and the children's exit code.  This parent never touches the GPU - it does not even count devices (every
@@ -460,9 +527,10 @@ def main():
     ap.add_argument("--proposals", type=int, default=16, help="proposals per track (P)")
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--seq-len", type=int, default=11)
-    ap.add_argument("--precision", choices=["x3", "f32", "f16"], default=os.environ.get("BUSCA_BENCH_PRECISION", "x3"),
-                    help="arithmetic of the primary line (default: the library's default flavour, x3 = float32-equivalent GEMMs as three fp16 MFMAs per "
-                         "product block; f32 = exact float32 MFMA); the others are reported under `variants`")
+    ap.add_argument("--precision", choices=["f32", "x3", "f16"], default=os.environ.get("BUSCA_BENCH_PRECISION", "f32"),
+                    help="arithmetic of the primary line (default f32 = exact float32 MFMA, the reference's own arithmetic; x3 = the library's default "
+                         "flavour, float32-equivalent GEMMs as three fp16 MFMAs per product block); the others are reported under `variants`")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where rank 0 writes everything it measured ('' = nowhere)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="independent steps handed to one C-ABI call; 0 = automatic: the K timed steps as ceil(K/64) launches of "
                          "near-equal size, so a short run is ONE launch whose workgroups back-fill the CUs round after round")
@@ -480,6 +548,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))      # before anything touches the GPU
 
+    contract_out, sys.stdout = sys.stdout, sys.stderr        # stdout carries the contract line and nothing else: stray prints of any leg go to stderr
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -586,38 +655,41 @@ def main():
         }
         if split is not None:
             result["configs"] = {"cfg5_split": split}
-    # ---- secondary precision + full step (rank 0, outside the contract's timed region) ---------------------------
+    # ---- the other precisions (rank 0, outside the contract's timed region) ------------------------------------------
     if rank == 0 and not args.no_variants:
         result["variants"] = {}
         r2 = None
-        for other in [q for q in ("f32", "x3", "f16") if q != args.precision]:
-            # the f16 flavour packs two tracks per workgroup from 257 tracks on: give it two rounds of workgroups (16 steps)
-            F2 = 16 if other == "f16" else 8
-            big2 = synth.dt_inputs(seed + 1000 * rank, B * F2, L, P)
-            tens2 = {k: torch.from_numpy(v).to(dev) for k, v in big2.items()}
-            rv = DTRunner(ctx, sd, other, tens2, B, L, P, F2, dev)
-            k2 = 1600                 # these legs are outside the contract's timed region: their own step count, whole launches only
-            rv.run_steps(160)
+
+        def variant(prec, Fv, k, key, note):
+            tv = tens
+            if Fv != F:
+                tv = {kk: torch.from_numpy(v).to(dev) for kk, v in synth.dt_inputs(seed + 1000 * rank, B * Fv, L, P).items()}
+            rv = DTRunner(ctx, sd, prec, tv, B, L, P, Fv, dev)
+            rv.run_steps(max(Fv, k // 10))
             torch.cuda.synchronize(dev)
             a = time.perf_counter()
-            nl2 = rv.run_steps(k2)
+            nl = rv.run_steps(k)
             torch.cuda.synchronize(dev)
-            el2 = time.perf_counter() - a
-            tm2 = rv.kernel_time(min(k2, 50 * F2))
-            if not tm2[1]:
-                tm2 = (el2 * 1e3, nl2, nl2, k2)
-            result["variants"][other] = {"value": k2 / el2, "unit": "steps/s", "steps": k2, "n_gpus": 1, "dtype": other, "steps_in_flight_per_launch": F2,
-                                         "p50_latency_ms": rv.p50_latency_ms(min(args.latency_samples, 300)),
-                                         "roofline": roofline_obj(other, B, L, P, d, ff, tm2, el2 / nl2 * 1e3, geometry=rv.geometry())}
+            el = time.perf_counter() - a
+            tm = rv.kernel_time(min(k, 50 * Fv))
+            if not tm[1]:
+                tm = (el * 1e3, nl, nl, k)
+            result["variants"][key] = {"value": k / el, "unit": "steps/s", "steps": k, "n_gpus": 1, "dtype": prec, "steps_in_flight_per_launch": Fv, "note": note,
+                                       "roofline": roofline_obj(prec, B, L, P, d, ff, tm, el / nl * 1e3, geometry=rv.geometry())}
+            return rv
+
+        for other in [q for q in ("f32", "x3", "f16") if q != args.precision]:
+            # (a) the launch shape of the primary line (F steps per launch), launches queued back to back
+            rv = variant(other, F, F * max(1, 400 // F), other, "same steps per launch as the primary line, launches queued back to back")
+            result["variants"][other]["p50_latency_ms"] = rv.p50_latency_ms(min(args.latency_samples, 300))
+            # (b) whole rounds of workgroups: 8 steps = 256 one-track workgroups on 256 CUs (the f16 flavour packs two tracks per workgroup from
+            # 257 tracks on: 16 steps)
+            F2 = 16 if other == "f16" else 8
+            rw = variant(other, F2, 1600, other + "_whole_rounds", "launches of %d steps = whole rounds of workgroups on 256 CUs" % F2)
             if other == "f16":
-                r2 = rv
-            if other == "f32":      # the exact flavour at the driver's step count too (one launch of 20 steps: two whole rounds + the token-split tail)
-                t20 = synth.dt_inputs(seed + 1000 * rank, B * 20, L, P)
-                r20 = DTRunner(ctx, sd, "f32", {k: torch.from_numpy(v).to(dev) for k, v in t20.items()}, B, L, P, 20, dev)
-                r20.run_steps(40)
-                tm20 = r20.kernel_time(200)
-                result["variants"]["f32_steps20"] = {"dtype": "f32", "steps_in_flight_per_launch": 20, "value": 200 / (tm20[0] * 1e-3) if tm20[0] > 0 else None, "unit": "steps/s (kernel time)",
-                                                     "roofline": roofline_obj("f32", B, L, P, d, ff, tm20, tm20[0] / max(1, tm20[2]), geometry=r20.geometry())}
+                r2 = rw
+        if F != 8:
+            variant(args.precision, 8, 1600, args.precision + "_whole_rounds", "launches of 8 steps = one whole round of workgroups on 256 CUs")
         # the other BASELINE shapes as their own DT-step lines (cfgR = shipped model shape; cfg4 = BASELINE configs[3];
         # cfg5 = BASELINE configs[4], one GPU's share is the full 512-track step here)
         cfgs = result.setdefault("configs", {})
@@ -686,7 +758,7 @@ def main():
         except Exception as e:      # the end-to-end leg is informative, never fatal for the contract line
             result["assoc_e2e"] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result, args.detail, contract_out)
 
 
 if __name__ == "__main__":
