@@ -67,6 +67,8 @@ struct BuscaOptions {
     int dt_split = -1;        // BUSCA_DT_SPLIT: token-split tail of the fused kernel (two workgroups per track): -1 = when the last round of a launch would fill at most
                               // half of the CUs, 0 = never, 1 = as many of the last tracks as fit one round (tests)
     int dt_prof = 0;          // BUSCA_DT_PROF: phase stamps of the fused kernel (debug): 1 = the one-workgroup flavour, 2 = the token-split flavour (first tile's workgroup)
+    int dt_exact_f32 = 0;     // 1 = a context loaded with BUSCA_PREC_F16X3 runs its forwards in exact float32 (the f32 fragment packing kept beside the split one):
+                              // how the host re-runs a step whose x3 forward reported a clipped operand ("dt_status" 2)
     int crop_band = 1;        // BUSCA_CROP_BAND: 1 = crops through the LDS-staged band kernel (crop_band_kernel), 0 = one thread per output pixel (A/B, tests)
     int last_dt_grid = 0, last_dt_ntrk = 0, last_dt_split = 0;     // read-only: workgroups / tracks per workgroup / token-split tracks of the last fused launch
     static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -189,6 +191,8 @@ extern "C" int busca_set_option(busca_ctx* c, const char* name, int32_t value) {
     else if (n == "dtl_ffn") o.dtl_ffn = value;
     else if (n == "dtl_attn") o.dtl_attn = value;
     else if (n == "crop_band") o.crop_band = value;
+    else if (n == "dt_exact_f32") o.dt_exact_f32 = value != 0;
+    else if (n == "dt_status") { if (c->dt.xerr) *c->dt.xerr = value; }      // 0 = the caller has read the status of its synchronised forward and dealt with it
     else return fail(c, BUSCA_EINVAL, "busca_set_option: unknown option '%s'", name);
     return BUSCA_OK;
 }
@@ -204,13 +208,15 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
     if (n == "dt_ntrk") *value = o.dt_ntrk;
     else if (n == "dt_split") *value = o.dt_split;
     else if (n == "last_dt_split") *value = o.last_dt_split;
-    else if (n == "dt_status") *value = c->dt.xerr ? *c->dt.xerr : 0;       // 0 ok, 1 a split launch lost a partner, 2 an x3 forward clipped an operand (also reported by the next forward)
+    else if (n == "dt_status") *value = c->dt.xerr ? *c->dt.xerr : 0;       // 0 ok, 1 a split launch lost a partner, 2 an x3 forward clipped an operand; valid once the forward's stream is
+                                                                            // synchronised; cleared by busca_set_option("dt_status", 0) (an uncleared status is also returned by the next forward)
     else if (n == "dt_tiled") *value = o.dt_tiled;
     else if (n == "dtl_rt") *value = o.dtl_rt;
     else if (n == "dtl_rt_mask") *value = o.dtl_rt_mask;
     else if (n == "dtl_ffn") *value = o.dtl_ffn;
     else if (n == "dtl_attn") *value = o.dtl_attn;
     else if (n == "crop_band") *value = o.crop_band;
+    else if (n == "dt_exact_f32") *value = o.dt_exact_f32;
     else if (n == "last_dt_grid") *value = o.last_dt_grid;
     else if (n == "last_dt_ntrk") *value = o.last_dt_ntrk;
     else return fail(c, BUSCA_EINVAL, "busca_get_option: unknown option '%s'", name);
@@ -819,10 +825,9 @@ extern "C" int busca_dt_reserve(busca_ctx* c, int32_t B, int32_t L, int32_t P, v
     return dtl_ws_ensure(c, dtl_ws_bytes((size_t)B * (L + 2 * (P + c->dt.proto.nspec)), c->dt.cfg.d, c->dt.cfg.ff, es), (hipStream_t)stream);
 }
 
-extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
-                                const float* can_ltrb, int32_t B, int32_t L, int32_t P, float* logits, float* probs,
-                                int32_t* argmax, float* hidden, float* att, void* stream) {
-    if (!c) return BUSCA_EINVAL;
+static int dt_forward_impl(busca_ctx* c, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
+                           const float* can_ltrb, int32_t B, int32_t L, int32_t P, float* logits, float* probs,
+                           int32_t* argmax, float* hidden, float* att, void* stream) {
     if (!c->dt.loaded) return fail(c, BUSCA_ENOWEIGHTS, "busca_dt_forward before busca_dt_load_weights");
     if (B < 0 || L < 1 || P < 1 || !logits) return fail(c, BUSCA_EINVAL, "bad shape B=%d L=%d P=%d or null logits", B, L, P);
     if (B == 0) return BUSCA_OK;
@@ -831,16 +836,15 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
     K.mem_feat = mem_feat; K.can_feat = can_feat; K.mem_ltrb = mem_ltrb; K.can_ltrb = can_ltrb;
     K.logits = logits; K.probs = probs; K.argmax = argmax; K.hidden = hidden; K.att = att;
     K.B = B; K.L = L; K.P = P; K.T = L + 2 * (P + K.nspec);
-    if (c->dt.xerr && *c->dt.xerr) {         // written by a kernel of an EARLIER call (host-mapped memory): reported once, then cleared
-        const int st = *c->dt.xerr;
-        *c->dt.xerr = 0;
-        if (st == 2) return fail(c, BUSCA_EINVAL, "an earlier Decision-Transformer forward clipped activations beyond the split-fp16 (BUSCA_PREC_F16X3) operand range "
-                                                  "(|x| > 1023.5): its results were not float32-equivalent; load this model with BUSCA_PREC_F32");
-        return fail(c, BUSCA_EHIP, "an earlier token-split Decision-Transformer launch gave up waiting for a partner workgroup: its results were invalid");
-    }
     K.xerr = c->dt.xerr_dev;
     const int MT = (K.T + 15) / 16;
-    const int d = c->dt.cfg.d, prec = c->dt.cfg.precision;
+    const int d = c->dt.cfg.d;
+    int prec = c->dt.cfg.precision;
+    if (prec == BUSCA_PREC_F16X3 && c->opt.dt_exact_f32) {      // exact float32 on the f32 fragment packing of the same matrices (how the host re-runs a clipped x3 step)
+        prec = BUSCA_PREC_F32;
+        K.w_embed = c->dt.proto32.w_embed;
+        for (int l = 0; l < K.nlayers; ++l) { K.layer[l].w_in = c->dt.proto32.layer[l].w_in; K.layer[l].w_out = c->dt.proto32.layer[l].w_out; K.layer[l].w1 = c->dt.proto32.layer[l].w1; K.layer[l].w2 = c->dt.proto32.layer[l].w2; }
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool force_tiled = c->opt.dt_tiled != 0;          // testing: run the layer-wise path on any shape
     // the one-kernel path is built for the shipped geometry (four heads, ff = 2 d); other head counts / widths run layer-wise
@@ -882,6 +886,22 @@ extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float
         if (d == 512) return dt_forward_tiled<0, 512>(c, K, s);
     }
     return fail(c, BUSCA_EINVAL, "no Decision-Transformer kernel for T=%d (tiles %d), d=%d", K.T, MT, d);
+}
+
+extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
+                                const float* can_ltrb, int32_t B, int32_t L, int32_t P, float* logits, float* probs,
+                                int32_t* argmax, float* hidden, float* att, void* stream) {
+    if (!c) return BUSCA_EINVAL;
+    // Backstop for callers that never read "dt_status" after synchronising (busca_amd's own wrappers do, and re-run a clipped step in exact f32): a status a
+    // kernel of an EARLIER call left in host-mapped memory is taken here, THIS call's kernels are launched all the same, and the earlier failure is returned.
+    int st = 0;
+    if (c->dt.xerr && *c->dt.xerr) { st = *c->dt.xerr; *c->dt.xerr = 0; }
+    const int rc = dt_forward_impl(c, mem_feat, can_feat, mem_ltrb, can_ltrb, B, L, P, logits, probs, argmax, hidden, att, stream);
+    if (rc != BUSCA_OK || st == 0) return rc;
+    if (st == 2) return fail(c, BUSCA_EINVAL, "an EARLIER Decision-Transformer forward clipped activations beyond the split-fp16 (BUSCA_PREC_F16X3) operand range (|x| > 1023.5): "
+                                              "its results were not float32-equivalent (re-run it with busca_set_option(\"dt_exact_f32\", 1) or load the model with BUSCA_PREC_F32); "
+                                              "this call's kernels were launched normally");
+    return fail(c, BUSCA_EHIP, "an EARLIER token-split Decision-Transformer launch gave up waiting for a partner workgroup: its results were invalid; this call's kernels were launched normally");
 }
 
 extern "C" int busca_dt_bucket_ids(busca_ctx* c, const float* mem_ltrb, const float* can_ltrb, int32_t B, int32_t L,

@@ -46,6 +46,8 @@ class DecisionTransformerHIP:
                                   "d/nhead in 16/32/64/128, ff a multiple of d up to 8 d, E = 512)" % (d, ff, self.nhead, nl, E))
         assert self._blob.size == want, (self._blob.size, want)
         self._luts = weights.encoding_luts(d)
+        self._rerun = {}            # x3: id(logits) -> (weakref, inputs) of forwards not settled yet (see settle)
+        self.exact_reruns = 0       # steps settle() re-ran in exact float32 because the x3 forward reported a clipped operand
         self._upload()
 
     def _upload(self):
@@ -89,7 +91,45 @@ class DecisionTransformerHIP:
             self.ctx.h, mem_feat.data_ptr(), can_feat.data_ptr(), mem_ltrb.data_ptr(), can_ltrb.data_ptr(), B, L, P,
             out["logits"].data_ptr(), out["probs"].data_ptr(), out["argmax"].data_ptr(),
             _lib.ptr(out.get("hidden")), _lib.ptr(out.get("att")), s))
+        if self.precision == "x3":     # what settle() needs to run the step once more (keeps the inputs alive as long as the outputs)
+            self._rerun[id(out["logits"])] = (weakref.ref(out["logits"]), (mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden, want_att, stream))
+            if len(self._rerun) > 64:
+                self._rerun = {k: v for k, v in self._rerun.items() if v[0]() is not None}
         return out
+
+    def settle(self, out):
+        """Call once the stream of `out`'s forward is SYNCHRONISED (the caller has just copied logits / probabilities to the host) and before the results are
+        used.  Reads the status word the kernels leave in host-mapped memory (`dt_status`, include/busca_hip.h):
+          0  -> `out` as it is;
+          2  -> the x3 forward had to clip an operand beyond |x| = 1023.5, its results are not float32-equivalent: the SAME step is run again in exact float32
+                on the f32 packing of the same weights (`dt_exact_f32`), synchronised, and THAT result is returned - the caller never sees a clipped step and
+                nothing is raised (the reference, busca/network.py:401-405, cannot fail there either);
+          1  -> a token-split launch lost a partner workgroup: raised for THIS call.
+        The status is cleared either way, so the C-side backstop of the next busca_dt_forward stays silent."""
+        st = self.ctx.get_option("dt_status")
+        if st == 0:
+            self._rerun.pop(id(out["logits"]), None)
+            return out
+        self.ctx.set_option("dt_status", 0)
+        if st != 2:
+            raise _lib.BuscaError("a token-split Decision-Transformer launch gave up waiting for a partner workgroup: the results of this forward are invalid")
+        ent = self._rerun.pop(id(out["logits"]), None)
+        if ent is None or ent[0]() is not out["logits"]:
+            raise _lib.BuscaError("an x3 Decision-Transformer forward clipped an operand (|x| > 1023.5) and its inputs are gone: load the model with precision='f32'")
+        mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden, want_att, stream = ent[1]
+        self.exact_reruns += 1
+        self.ctx.set_option("dt_exact_f32", 1)
+        try:
+            self._ensure_loaded()
+            fixed = self.forward(mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=want_hidden, want_att=want_att, stream=stream)
+        finally:
+            self.ctx.set_option("dt_exact_f32", 0)
+        self._rerun.pop(id(fixed["logits"]), None)
+        if stream is None:
+            torch.cuda.current_stream(torch.device("cuda", self.ctx.device)).synchronize()
+        else:
+            torch.cuda.synchronize(torch.device("cuda", self.ctx.device))
+        return fixed
 
     def can_positions(self, L, P):
         """Rows of the candidate tokens (incl. NON [, BAD]) in the token sequence (network.py:142,154)."""

@@ -462,7 +462,14 @@ class BUSCA:
             pos = self._dt.can_positions(L, P)
             self.logits = out["hidden"][:, pos]
             self.mem_logits = out["hidden"][:, :L].mean(dim=1)
-        probs = out["probs"].cpu().numpy().astype(np.float64)
+        probs = out["probs"].cpu().numpy().astype(np.float64)                 # (synchronises the forward's stream)
+        fixed = self._dt.settle(out)            # an x3 forward that clipped an operand is run again in exact float32: the tracker never gets a clipped step
+        if fixed is not out:
+            out = self._last = fixed
+            probs = out["probs"].cpu().numpy().astype(np.float64)
+            if self.store_logits and "hidden" in out:
+                self.logits = out["hidden"][:, self._dt.can_positions(L, P)]
+                self.mem_logits = out["hidden"][:, :L].mean(dim=1)
         best = out["argmax"].cpu().numpy()
         cols = N if K == 0 else N + K
         probs_matrix = np.zeros((B, cols))

@@ -544,3 +544,33 @@ def test_decisions_next_to_the_half_threshold():
             assert c["abs_delta_prob"]["max"] <= 5e-3 and c["kalman_gt_0.5"]["flip_rate"] <= 2e-3 and c["winner"]["flip_rate"] <= 2e-3
         else:
             assert c["kalman_gt_0.5"]["flips"] <= near and c["kalman_gt_0.5"]["flip_rate"] <= 0.05
+
+
+def test_associate_never_returns_a_clipped_x3_step(golden_dir):
+    """A checkpoint whose activations leave the split-fp16 operand range (LayerNorm weights x 3000 -> |x| ~ 9000 > 1023.5): the default x3 Decision Transformer
+    clips, raises `dt_status` 2, and associate_embeddings - already synchronised on the probabilities - runs that step again in exact float32 and returns THAT:
+    the f32 flavour's probabilities bit for bit, no exception in this frame or the next (busca/network.py:401-405 cannot fail there)."""
+    from busca_amd.network import BUSCA
+
+    def build(prec):
+        a = _args(precision=prec)
+        a.reid_precision = "x3"
+        m = BUSCA(a).to(torch.device("cuda:0")).eval()
+        sd = dict(synth.dt_state_dict(17, d=64, ff=128))
+        sd["transformer_encoder.layers.1.norm1.weight"] = sd["transformer_encoder.layers.1.norm1.weight"] * 3000.0
+        sd.update({"reid_encoder.model." + k: v for k, v in synth.reid_state_dict(17).items()})
+        m.load_state_dict(sd)
+        return m
+
+    g = np.load(os.path.join(golden_dir, "assoc.npz"))
+    name, tracks, dets, kals, P = _case(1)
+    dists = g[name + "_dists"]
+    m32, m3 = build("f32"), build("x3")
+    want, rel32 = m32.associate_embeddings(tracks, dets, dists, 11, P, True, False, extra_kalman_candidates=kals, normalize_ims=True)
+    for frame in range(2):               # twice: the re-run leaves nothing behind for the next frame to trip over
+        got, rel = m3.associate_embeddings(tracks, dets, dists, 11, P, True, False, extra_kalman_candidates=kals, normalize_ims=True)
+        assert np.array_equal(got, want) and np.array_equal(rel, rel32)
+        assert m3._dt.exact_reruns == frame + 1 and m3._ctx.get_option("dt_status") == 0
+    got1, _ = m3.associate_embeddings(tracks, dets, dists, 11, P, True, True, extra_kalman_candidates=kals, normalize_ims=True)
+    want1, _ = m32.associate_embeddings(tracks, dets, dists, 11, P, True, True, extra_kalman_candidates=kals, normalize_ims=True)
+    assert np.array_equal(got1, want1)

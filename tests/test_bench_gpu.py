@@ -17,9 +17,12 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 MAX_LINE = 6000        # the driver keeps about 8 KB of stdout; round 5's 24 KB line did not parse
 
 
-def _last_json(out):
-    """stdout must be exactly ONE line, short enough for the driver to keep whole, and it must parse."""
+def _last_json(out, launcher_noise=False):
+    """stdout must be exactly ONE line, short enough for the driver to keep whole, and it must parse.  (Under torch.distributed.run the gloo test backend's
+    C++ prints its own "[Gloo] Rank ..." lines on the children's stdout: those runs must hold exactly one JSON line.)"""
     lines = out.strip().splitlines()
+    if launcher_noise:
+        lines = [l for l in lines if not l.startswith("[Gloo]")]
     assert len(lines) == 1 and lines[0].startswith("{"), out[-2000:]
     assert len(lines[0]) <= MAX_LINE, len(lines[0])
     return json.loads(lines[0])
@@ -87,7 +90,7 @@ def test_bench_two_ranks_code_path(tmp_path):
                         "--cpu-seconds", "0", "--latency-samples", "0", "--split-steps", "0", "--detail", str(tmp_path / "d.json")],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    _check_two_ranks(_last_json(r.stdout), json.load(open(str(tmp_path / "d.json"))))
+    _check_two_ranks(_last_json(r.stdout, True), json.load(open(str(tmp_path / "d.json"))))
 
 
 def test_bench_self_launches_ranks_and_splits_cfg5(tmp_path):
@@ -100,7 +103,7 @@ def test_bench_self_launches_ranks_and_splits_cfg5(tmp_path):
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--detail", str(tmp_path / "d2.json")] + common,
                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r2.returncode == 0, r2.stderr[-2000:]
-    d2 = _last_json(r2.stdout)
+    d2 = _last_json(r2.stdout, True)
     f2 = json.load(open(str(tmp_path / "d2.json")))
     _check_two_ranks(d2, f2)
     assert d2["configs"]["cfg5_split"]["n_gpus"] == 2 and d2["configs"]["cfg5_split"]["value"] > 0
@@ -112,7 +115,7 @@ def test_bench_self_launches_ranks_and_splits_cfg5(tmp_path):
                          "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--detail", str(tmp_path / "d1.json")] + common,
                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env1)
     assert r1.returncode == 0, r1.stderr[-2000:]
-    _last_json(r1.stdout)
+    _last_json(r1.stdout, True)
     s1 = json.load(open(str(tmp_path / "d1.json")))["configs"]["cfg5_split"]
     assert s1["n_gpus"] == 1 and s1["track_slices"] == [[0, 512]]
     assert s1["logits_sha256"] == s2["logits_sha256"] and s1["argmax_sha256"] == s2["argmax_sha256"]

@@ -223,24 +223,43 @@ def test_token_split_tail_is_bit_identical(ctx, prec, pair, shape):
 
 def test_x3_reports_operands_beyond_its_range(ctx):
     """The split-fp16 flavour carries activations as fp16 hi + lo of 64 x: |x| > 1023.5 cannot be represented.  Such a forward is not clipped silently -
-    the kernel raises a status word in host-mapped memory (`dt_status` 2) and the next forward of the context fails with the reason; weights beyond
-    |w| = 255 are refused when they are loaded.  The exact f32 flavour takes both."""
+    the kernel raises a status word in host-mapped memory (`dt_status` 2).  `DecisionTransformerHIP.settle` (called by every busca_amd path that hands
+    probabilities to a tracker, once it has synchronised) then runs the SAME step again in exact float32 on the f32 packing of the same weights and returns
+    that result - bit for bit what the f32 flavour gives, nothing raised (busca/network.py:401-405 cannot fail there).  A raw C-ABI caller that never
+    reads the status gets the reason from its next busca_dt_forward (whose kernels are launched all the same).  Weights beyond |w| = 255 are refused when
+    they are loaded.  The exact f32 flavour takes both."""
     from busca_amd import _lib
     from busca_amd.dt import DecisionTransformerHIP
     sd = synth.dt_state_dict(11, d=256, ff=512)
     inp = synth.dt_inputs(11, 8, 11, 16)
+    args = (inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])
     out, m = _run(ctx, sd, inp, "x3", True)
     assert ctx.get_option("dt_status") == 0
     hot = dict(sd)
     hot["transformer_encoder.layers.1.norm1.weight"] = sd["transformer_encoder.layers.1.norm1.weight"] * 3000.0     # LayerNorm outputs of ~ +-9000
-    _run(ctx, hot, inp, "f32", True)                    # fine in exact f32
+    want, _ = _run(ctx, hot, inp, "f32", True, want_hidden=True)                    # fine in exact f32
     assert ctx.get_option("dt_status") == 0
-    _, mh = _run(ctx, hot, inp, "x3", True)             # (_run synchronises)
+    mh = DecisionTransformerHIP(ctx, hot, activation="relu", fake_bbox_f64=True, precision="x3")
+    o = mh.forward(*args, want_hidden=True)
+    torch.cuda.synchronize()
     assert ctx.get_option("dt_status") == 2
-    with pytest.raises(_lib.BuscaError, match="split-fp16"):
-        mh.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])
+    clipped = o["logits"].cpu().numpy()
+    fixed = mh.settle(o)                                 # the step again, exact float32, synchronised
+    assert fixed is not o and mh.exact_reruns == 1 and ctx.get_option("dt_status") == 0 and ctx.get_option("dt_exact_f32") == 0
+    for k in ("logits", "probs", "argmax", "hidden"):
+        assert np.array_equal(fixed[k].cpu().numpy(), want[k]), k
+    assert not np.array_equal(clipped, want["logits"])
+    ok = m.forward(*args)                                # a healthy x3 model on the same context: nothing to settle
+    torch.cuda.synchronize()
+    assert m.settle(ok) is ok and np.array_equal(ok["logits"].cpu().numpy(), out["logits"])
+    # the C-side backstop: a caller that never reads the status hears about the clipped forward from its NEXT call - which still runs
+    o2 = mh.forward(*args)
+    torch.cuda.synchronize()
+    assert ctx.get_option("dt_status") == 2
+    with pytest.raises(_lib.BuscaError, match="EARLIER.*split-fp16"):
+        m.forward(*args)
     assert ctx.get_option("dt_status") == 0             # reported once
-    again = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"])
+    again = m.forward(*args)
     torch.cuda.synchronize()
     assert np.array_equal(again["logits"].cpu().numpy(), out["logits"]) and ctx.get_option("dt_status") == 0
     big = dict(sd)
