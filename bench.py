@@ -312,6 +312,13 @@ def assoc_e2e(frames):
     r = e2e_sim.run(8, 60, 5, 512, frames=frames, verbose=False, device_only_crops=True)     # opt-in: crops never copied back to the host (default flavour)
     out["lost8_dets52_device_only_crops"] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "busca_frames_per_s", "precision", "reid_precision")}
     gc.collect(); torch.cuda.empty_cache()
+    try:        # the call pattern of the UNCHANGED StrongSORT / GHOST adapters: one get_image_crops per detection, no frame scope (each call reads the live host frame
+                # and uploads the sub-frame its box needs, geometry._frame_for_rects)
+        r = e2e_sim.run(8, 60, 5, 512, frames=frames, verbose=False, per_detection_crops=True)
+        out["lost8_dets52_one_crop_call_per_detection"] = {k: r[k] for k in ("p50_assoc_latency_ms", "p50_crop_ms", "crop_calls_per_frame", "busca_frames_per_s")}
+        gc.collect(); torch.cuda.empty_cache()
+    except Exception as e:
+        out["lost8_dets52_one_crop_call_per_detection"] = {"error": repr(e)}
     try:        # several trackers on one GPU: the steps of one frame interval through the StepBatcher (one DT launch), default flavour
         out["multi_sequence_4x_lost8"] = e2e_sim.run_multi(4, 8, 60, 5, 512, frames=frames)
     except Exception as e:

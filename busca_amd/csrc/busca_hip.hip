@@ -1,123 +1,15 @@
-// libbusca_hip.so - C-ABI entry points (include/busca_hip.h) and host-side plumbing.
-// gfx950 only.  Kernels live in the *.hip.inc files included below (one translation unit keeps the
-// build a single hipcc invocation).
-#include <hip/hip_runtime.h>
-#include <hip/hip_fp16.h>
+// libbusca_hip.so, core unit - C-ABI of include/busca_hip.h over the HIP kernels in this directory (the other units: busca_internal.hpp).
+// Written for gfx950 (MI355X) only.  hipcc --offload-arch=gfx950 (see busca_amd/build.py).
+#include "busca_internal.hpp"
 
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <set>
-#include <string>
-#include <type_traits>
-#include <vector>
-
-#include "../../include/busca_hip.h"
-
+#define BUSCA_DT_BUCKET_KERNEL 1
 #include "dt_kernel.hip.inc"
 #include "pairwise_kernel.hip.inc"
 #include "track_kernel.hip.inc"
 #include "crop_kernel.hip.inc"
-#include "reid_kernel.hip.inc"
-#include "reid_gram.hip.inc"
-#include "reid_halo.hip.inc"
-#include "reid_kwave.hip.inc"
-#include "reid_pipe.hip.inc"
-#include "reid_f32.hip.inc"
-#include "reid_x3.hip.inc"
-#include "reid_x3p.hip.inc"
-#include "dt_tiled.hip.inc"
 #include "ecc_kernel.hip.inc"
 
-// ---------------------------------------------------------------------------------------------------------
-struct DTTiledW {                   // row-major copies of the matrices for the tiled path, in the operand type (f16 or f32)
-    const void* w_embed = nullptr;
-    const void *w_in[DT_MAX_LAYERS] = {}, *w_out[DT_MAX_LAYERS] = {}, *w1[DT_MAX_LAYERS] = {}, *w2[DT_MAX_LAYERS] = {};
-};
-
-struct DTState {
-    bool loaded = false;
-    busca_dt_cfg cfg{};
-    void* dev_blob = nullptr;      // one allocation holding every packed matrix / vector / LUT
-    size_t dev_bytes = 0;
-    DTParams proto{};              // weight pointers filled in, per-call fields zero
-    void* dev_blob32 = nullptr;    // x3 only: the matrices once more, packed for the exact f32 kernels (the layer-wise path of shapes beyond the one-kernel path)
-    DTParams proto32{};            // = proto with the matrix pointers into dev_blob32
-    void* dev_tiled = nullptr;     // row-major f16 matrices (tiled path)
-    DTTiledW tw;
-    void* ws = nullptr; size_t ws_bytes = 0;   // tiled-path activation workspace
-    // token-split tail of the fused kernel (dt_fused_kernel<..., SPLIT = true>): K / V exchange tiles, flags, decoder hand-over of up to xslots tracks; xepoch
-    // numbers the launches (flags only ever grow, nothing is cleared between launches); xerr is host memory the kernel writes if a wait ran out
-    void* xch = nullptr; unsigned* xflag = nullptr; float* xlg = nullptr; int* xerr = nullptr; int* xerr_dev = nullptr; int xslots = 0; unsigned xepoch = 0;
-    int num_cu = 256;
-};
-
-// Developer options of one context.  Defaults come from the environment ONCE, when the context is created; afterwards they
-// change only through busca_set_option (so a test can flip a flavour between two forwards, and no forward calls getenv).
-struct BuscaOptions {
-    int dt_ntrk = 0;          // BUSCA_DT_NTRK: tracks per workgroup of the f16 fused kernel (0 = automatic: 2 from B > 256, d = 256)
-    int dt_tiled = 0;         // BUSCA_DT_TILED: force the layer-wise Decision-Transformer path
-    int dtl_rt = 0;           // BUSCA_DTL_RT: 2 / 4 = 64- / 128-row tiles of the layer-wise GEMMs (0 = automatic)
-    int dtl_rt_mask = -1;     // BUSCA_DTL_RT_MASK: bit EPI = 64-row tiles for that GEMM kind (-1 = off)
-    int dtl_ffn = 2;          // BUSCA_DTL_FFN: 2 = the layer-wise path runs out-proj + norm1 + feed-forward + norm2 as ONE kernel, 1 = the feed-forward block only,
-                              // 0 = one kernel per GEMM (H and x1 through HBM)
-    int dtl_attn = 1;         // BUSCA_DTL_ATTN: 1 = QKV projection + attention of a (track, head) in one kernel where it is built (0: QKV GEMM + attention kernel)
-    int dt_split = -1;        // BUSCA_DT_SPLIT: token-split tail of the fused kernel (two workgroups per track): -1 = when the last round of a launch would fill at most
-                              // half of the CUs, 0 = never, 1 = as many of the last tracks as fit one round (tests)
-    int dt_prof = 0;          // BUSCA_DT_PROF: phase stamps of the fused kernel (debug): 1 = the one-workgroup flavour, 2 = the token-split flavour (first tile's workgroup)
-    int dt_exact_f32 = 0;     // 1 = a context loaded with BUSCA_PREC_F16X3 runs its forwards in exact float32 (the f32 fragment packing kept beside the split one):
-                              // how the host re-runs a step whose x3 forward reported a clipped operand ("dt_status" 2)
-    int crop_band = 1;        // BUSCA_CROP_BAND: 1 = crops through the LDS-staged band kernel (crop_band_kernel), 0 = one thread per output pixel (A/B, tests)
-    int last_dt_grid = 0, last_dt_ntrk = 0, last_dt_split = 0;     // read-only: workgroups / tracks per workgroup / token-split tracks of the last fused launch
-    static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-    void from_env() {
-        dt_ntrk = env_int("BUSCA_DT_NTRK", 0); dt_tiled = getenv("BUSCA_DT_TILED") != nullptr ? 1 : 0;
-        dtl_rt = env_int("BUSCA_DTL_RT", 0); dtl_rt_mask = env_int("BUSCA_DTL_RT_MASK", -1);
-        dt_prof = env_int("BUSCA_DT_PROF", 0); dt_split = env_int("BUSCA_DT_SPLIT", -1);
-        dtl_ffn = env_int("BUSCA_DTL_FFN", 2); dtl_attn = env_int("BUSCA_DTL_ATTN", 1); crop_band = env_int("BUSCA_CROP_BAND", 1);
-    }
-};
-
-struct busca_ctx {
-    int device = 0;
-    std::string err;
-    BuscaOptions opt;
-    DTState dt;
-    ReidState reid;
-    // kernel timing (HIP events on the launch stream)
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
-    std::vector<hipEvent_t> ev_free;
-    double t_ms = 0.0;
-    long long t_n = 0;
-    int* crop_fill = nullptr;      // per-crop pad value scratch (busca_crop_gather)
-    int crop_fill_cap = 0;
-    std::set<const void*> lds_configured;   // kernels whose dynamic-LDS limit was raised on THIS device
-    void* ecc_ws = nullptr; size_t ecc_ws_bytes = 0;    // busca_ecc_align scratch: 5 float images + partials
-};
-
-// Raise a kernel's dynamic LDS limit once per context (the attribute is per device, so a process driving several
-// GPUs through several contexts must set it for each).
-static int ensure_lds(busca_ctx* c, const void* kern, size_t bytes);
-
-static int fail(busca_ctx* c, int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (c) c->err = buf;
-    return code;
-}
-#define HIP_TRY(c, call)                                                                                   \
-    do {                                                                                                   \
-        hipError_t e__ = (call);                                                                           \
-        if (e__ != hipSuccess) return fail((c), BUSCA_EHIP, "%s -> %s", #call, hipGetErrorString(e__));     \
-    } while (0)
-
-static int ensure_lds(busca_ctx* c, const void* kern, size_t bytes) {
+int ensure_lds(busca_ctx* c, const void* kern, size_t bytes) {
     if (c->lds_configured.count(kern)) return BUSCA_OK;
     HIP_TRY(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     c->lds_configured.insert(kern);
@@ -143,6 +35,7 @@ extern "C" int busca_ctx_create(int device, busca_ctx** out) {
     busca_ctx* c = new busca_ctx();
     c->device = device;
     c->opt.from_env();
+    c->reid = reid_state_new();
     *out = c;
     return BUSCA_OK;
 }
@@ -152,36 +45,11 @@ extern "C" int busca_ctx_create(int device, busca_ctx** out) {
 #endif
 extern "C" const char* busca_build_info(void) { return "libbusca_hip gfx950 flags: " BUSCA_BUILD_FLAGS; }
 
-// ReID schedule knobs by name ("reid_gram", "reid_halo", ...): the same fields the BUSCA_REID_* environment variables set when weights are
-// loaded; through busca_set_option they change between two forwards of a loaded extractor (A/B runs, the tests that compare schedules).
-static int* reid_option_field(ReidState& R, const std::string& n) {
-    struct { const char* name; int* p; } tab[] = {
-        {"reid_gram", &R.gram_mode}, {"reid_halo_min", &R.halo_min_blocks}, {"reid_halo_half", &R.halo_half_blocks},
-        {"reid_halo_wpx", &R.halo_wpx}, {"reid_halo_wpx_min", &R.halo_wpx_min}, {"reid_gram_min", &R.gram_min_pixels}, {"reid_direct_rows", &R.direct_rows},
-        {"reid_fuse_ds_layers", &R.fuse_ds_layers}, {"reid_fuse_c1_layers", &R.fuse_c1_layers}, {"reid_kwave_blocks", &R.kwave_blocks},
-        {"reid_kwave_halo", &R.kwave_halo_blocks}, {"reid_kwave_nw", &R.kwave_nw}, {"reid_kwave_pt", &R.kwave_pt}, 
-        {"reid_pipe_min", &R.pipe_min_tiles}, {"reid_pipe_half", &R.pipe_half_blocks},
-        {"reid_x3_merge_layers", &R.x3_merge_layers}, {"reid_x3_half", &R.x3_half_blocks}, {"reid_x3_gram_min", &R.x3_gram_min}, {"reid_x3_merge_in_min", &R.x3_merge_in_min}, {"reid_x3_fuse_c1_min", &R.x3_fuse_c1_min}, {"reid_x3_narrow3", &R.x3_narrow3}, {"reid_x3_row3", &R.x3_row3}, {"reid_x3_ptail", &R.x3_ptail_min}};
-    for (auto& e : tab) if (n == e.name) return e.p;
-    return nullptr;
-}
-static bool* reid_option_flag(ReidState& R, const std::string& n) {
-    struct { const char* name; bool* p; } tab[] = {{"reid_halo", &R.halo}, {"reid_fuse_c1", &R.fuse_c1}, {"reid_fuse_c1_small", &R.fuse_c1_small},
-                                                   {"reid_stats2", &R.two_launch_stats}, {"reid_pipe_all", &R.pipe_all}, {"reid_x3_gram", &R.x3_gram}, {"reid_x3_merge_in", &R.x3_merge_in}, {"reid_x3_fuse_c1", &R.x3_fuse_c1}, {"reid_x3_stem_halo", &R.x3_stem_halo}, {"reid_x3_stem_u8", &R.x3_stem_u8}, {"reid_x3_stem_pool", &R.x3_stem_pool}};
-    for (auto& e : tab) if (n == e.name) return e.p;
-    return nullptr;
-}
-
 extern "C" int busca_set_option(busca_ctx* c, const char* name, int32_t value) {
     if (!c || !name) return BUSCA_EINVAL;
     BuscaOptions& o = c->opt;
     const std::string n(name);
-    if (n.rfind("reid_", 0) == 0) {
-        if (!c->reid.loaded) return fail(c, BUSCA_ENOWEIGHTS, "busca_set_option('%s'): ReID schedule options belong to a loaded extractor (load weights first)", name);
-        if (int* p = reid_option_field(c->reid, n)) { *p = value; return BUSCA_OK; }
-        if (bool* p = reid_option_flag(c->reid, n)) { *p = value != 0; return BUSCA_OK; }
-        return fail(c, BUSCA_EINVAL, "busca_set_option: unknown option '%s'", name);
-    }
+    if (n.rfind("reid_", 0) == 0) return reid_set_option(c, name, value);
     if (n == "dt_ntrk") o.dt_ntrk = value;
     else if (n == "dt_split") o.dt_split = value;
     else if (n == "dt_prof") o.dt_prof = value;
@@ -200,11 +68,7 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
     if (!c || !name || !value) return BUSCA_EINVAL;
     const BuscaOptions& o = c->opt;
     const std::string n(name);
-    if (n.rfind("reid_", 0) == 0) {
-        if (int* p = reid_option_field(c->reid, n)) { *value = *p; return BUSCA_OK; }
-        if (bool* p = reid_option_flag(c->reid, n)) { *value = *p ? 1 : 0; return BUSCA_OK; }
-        return fail(c, BUSCA_EINVAL, "busca_get_option: unknown option '%s'", name);
-    }
+    if (n.rfind("reid_", 0) == 0) return reid_get_option(c, name, value);
     if (n == "dt_ntrk") *value = o.dt_ntrk;
     else if (n == "dt_split") *value = o.dt_split;
     else if (n == "last_dt_split") *value = o.last_dt_split;
@@ -223,7 +87,7 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
     return BUSCA_OK;
 }
 
-static void timing_drain(busca_ctx* c) {
+void timing_drain(busca_ctx* c) {
     for (auto& pr : c->ev_pending) {
         float ms = 0.f;
         if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
@@ -252,7 +116,7 @@ extern "C" void busca_ctx_destroy(busca_ctx* c) {
     if (c->dt.xerr) hipHostFree(c->dt.xerr);
     if (c->crop_fill) hipFree(c->crop_fill);
     if (c->ecc_ws) hipFree(c->ecc_ws);
-    reid_free(c->reid);
+    reid_state_delete(c->reid);
     delete c;
 }
 
@@ -271,22 +135,12 @@ extern "C" int busca_timing_read(busca_ctx* c, double* avg_ms, int64_t* launches
     if (reset) { c->t_ms = 0.0; c->t_n = 0; }
     return BUSCA_OK;
 }
-static hipEvent_t timing_event(busca_ctx* c) {
+hipEvent_t timing_event(busca_ctx* c) {
     if (!c->ev_free.empty()) { hipEvent_t e = c->ev_free.back(); c->ev_free.pop_back(); return e; }
     hipEvent_t e;
     hipEventCreate(&e);
     return e;
 }
-struct TimedLaunch {   // RAII: records start/stop events around one kernel launch when timing is on
-    busca_ctx* c; hipStream_t s; hipEvent_t e0{}, e1{}; bool on;
-    TimedLaunch(busca_ctx* c_, hipStream_t s_) : c(c_), s(s_), on(c_->timing) {
-        if (on) { e0 = timing_event(c); e1 = timing_event(c); hipEventRecord(e0, s); }
-    }
-    ~TimedLaunch() {
-        if (on) { hipEventRecord(e1, s); c->ev_pending.emplace_back(e0, e1); if (c->ev_pending.size() > 4096) timing_drain(c); }
-    }
-};
-
 // ---------------------------------------------------------------------------------------------------------
 // Decision Transformer: weight blob -> device
 // ---------------------------------------------------------------------------------------------------------
@@ -506,221 +360,14 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
     return BUSCA_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// How many of the last tracks of a launch run token-split (one workgroup per 16-token tile, `parts` per track), and how many tracks share a workgroup
-// (*pair: 1 or 2).  The tracks of the last, partial round of one-track workgroups are spread over the CUs that round would leave idle: a single 32-track
-// step of three tiles runs on 96 CUs instead of 32 (0.46 -> 0.22 ms); 640 such tracks on 256 CUs are two rounds + 192 workgroups holding one tile index
-// of two tracks each (0.35 ms) instead of three rounds.  One track per workgroup is the faster flavour while its workgroups fit ONE pass over the CUs
-// (a one-tile workgroup is bound by its weight stream through the CU's vector memory path: two to a CU take twice as long); beyond that two tracks
-// share a workgroup, every streamed weight fragment feeding two tiles (f32 flavour, tracks of three tiles or more - with two tiles such a workgroup
-// would do a whole track's work).  A partial round too large for either stays one workgroup per track.
-static int dt_split_tracks(const busca_ctx* c, int B, int parts, int prec, bool can_pair, int* pair) {
-    const DTState& S = c->dt;
-    *pair = 1;
-    if (S.xslots <= 0 || c->opt.dt_split == 0 || parts > DT_XMAX_MT) return 0;
-    if (c->opt.dt_split > 0) {                // tests: 1 = one track per workgroup, 2 = two
-        *pair = (c->opt.dt_split == 2 && can_pair) ? 2 : 1;
-        return std::min(B, S.xslots / 2);
-    }
-    // (f16 is left alone: that kernel is bound by the weight stream, which every workgroup of a split track repeats - measured 0.083 vs 0.085 ms for a
-    // 32-track step, slower from one pass of workgroups on)
-    if (prec == BUSCA_PREC_F16) return 0;
-    const int rem = B % S.num_cu;
-    if (rem == 0 || rem + 1 > S.xslots) return 0;
-    // x3 is bound by the weight stream (L1 / L2), not by the MFMA: a partial round already runs faster than a full one (640 tracks 0.607 ms against
-    // 3 x 0.225) and split workgroups add weight traffic - they pay only while the launch is small (32-track step 0.183 -> 0.134 ms; 128 tracks of two
-    // tiles at d = 512: 0.407 -> 0.430)
-    if (prec == BUSCA_PREC_F16X3) return 2 * parts * rem <= S.num_cu ? rem : 0;
-    if (parts * rem <= S.num_cu) return rem;
-    if (can_pair && parts * ((rem + 1) / 2) <= S.num_cu) { *pair = 2; return rem; }
-    return 0;
-}
-
-static int dt_prof_report(busca_ctx* c, long long* d, int nwg, hipStream_t s) {
-    HIP_TRY(c, hipStreamSynchronize(s));
-    long long h[4 * DT_PROF_SLOTS];
-    HIP_TRY(c, hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipFree(d));
-    fprintf(stderr, "DT_PROF grid=%d:", nwg);
-    for (int w = 0; w < 4; ++w) {
-        fprintf(stderr, "\n w%d", w);
-        for (int i = 1; i < DT_PROF_SLOTS; ++i)
-            if (h[w * DT_PROF_SLOTS + i]) fprintf(stderr, " %d:%lld", i, h[w * DT_PROF_SLOTS + i] - h[w * DT_PROF_SLOTS]);
-    }
-    fprintf(stderr, "\n");
-    return BUSCA_OK;
-}
-
-template <int PREC, int MT, int D, int FF, int NCH, int NTRK>
-static int dt_launch_split(busca_ctx* c, const DTParams& P0, int nsplit, hipStream_t s) {
-    typedef DTLds<PREC, 1, D, FF, 512, NCH, NTRK> LD;
-    DTState& S = c->dt;
-    auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH, NTRK, true>;
-    const int nwg = ((nsplit + NTRK - 1) / NTRK) * MT;
-    DTParams P = P0;
-    P.nsingle = P.B - nsplit;
-    P.xepoch = ++S.xepoch; P.xch = (unsigned long long*)S.xch; P.xflag = S.xflag; P.xlg = S.xlg; P.xerr = S.xerr_dev;
-    { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
-    if (c->opt.dt_prof == 2) {
-        HIP_TRY(c, hipMalloc((void**)&P.prof, 4 * DT_PROF_SLOTS * sizeof(long long)));
-        HIP_TRY(c, hipMemset(P.prof, 0, 4 * DT_PROF_SLOTS * sizeof(long long)));
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LD::TOTAL, s, P);
-        return dt_prof_report(c, P.prof, nwg, s);
-    }
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LD::TOTAL, s, P);
-    return BUSCA_OK;
-}
-
-template <int PREC, int MT, int D, int FF, int NCH, int NTRK = 1>
-static int dt_launch(busca_ctx* c, const DTParams& P, hipStream_t s) {
-    typedef DTLds<PREC, MT, D, FF, 512, NCH, NTRK> LD;
-    static_assert(LD::TOTAL <= 160 * 1024, "LDS plan exceeds the 160 KiB of a CU");
-    auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH, NTRK>;
-    const int nwg = (P.B + NTRK - 1) / NTRK;
-    c->opt.last_dt_grid = nwg; c->opt.last_dt_ntrk = NTRK; c->opt.last_dt_split = 0;
-    if constexpr (MT >= 2 && MT <= DT_XMAX_MT && NTRK == 1) {
-        constexpr bool PAIR = PREC != 1 && MT >= 3;       // the two-tracks-per-workgroup split flavour: f32 / x3, three tiles or more (with two tiles it would do a whole track's work)
-        // (every flavour is configured by the first forward of a shape, whichever it takes: a later launch of another track count must not pay for it)
-        if (c->dt.xslots > 0) {
-            { int rc = ensure_lds(c, (const void*)dt_fused_kernel<PREC, MT, D, FF, 512, NCH, 1, true>, DTLds<PREC, 1, D, FF, 512, NCH, 1>::TOTAL); if (rc) return rc; }
-            if constexpr (PAIR) { int rc = ensure_lds(c, (const void*)dt_fused_kernel<PREC, MT, D, FF, 512, NCH, 2, true>, DTLds<PREC, 1, D, FF, 512, NCH, 2>::TOTAL); if (rc) return rc; }
-        }
-        { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
-        // whole rounds of one-track workgroups, then the tail's tracks one token tile per workgroup: ONE timed region (the step batch), two launches on the stream
-        int pair = 1;
-        const int nsplit = c->opt.dt_prof == 1 ? 0 : dt_split_tracks(c, P.B, MT, PREC, PAIR, &pair);
-        if (nsplit > 0) {
-            c->opt.last_dt_grid = P.B - nsplit + ((nsplit + pair - 1) / pair) * MT; c->opt.last_dt_split = nsplit; c->opt.last_dt_ntrk = pair;
-            TimedLaunch tl(c, s);
-            if (P.B > nsplit) hipLaunchKernelGGL(kern, dim3(P.B - nsplit), dim3(256), LD::TOTAL, s, P);
-            int rc = BUSCA_OK;
-            if constexpr (PAIR) { if (pair == 2) rc = dt_launch_split<PREC, MT, D, FF, NCH, 2>(c, P, nsplit, s); else rc = dt_launch_split<PREC, MT, D, FF, NCH, 1>(c, P, nsplit, s); }
-            else rc = dt_launch_split<PREC, MT, D, FF, NCH, 1>(c, P, nsplit, s);
-            if (rc) return rc;
-            HIP_TRY(c, hipGetLastError());
-            return BUSCA_OK;
-        }
-    }
-    { int rc = ensure_lds(c, (const void*)kern, LD::TOTAL); if (rc) return rc; }
-    const bool prof = c->opt.dt_prof == 1;   // debug: phase timestamps of workgroup 0
-    if (prof) {
-        DTParams Q = P;
-        long long* d = nullptr;
-        HIP_TRY(c, hipMalloc((void**)&d, 4 * DT_PROF_SLOTS * sizeof(long long)));
-        HIP_TRY(c, hipMemset(d, 0, 4 * DT_PROF_SLOTS * sizeof(long long)));
-        Q.prof = d;
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LD::TOTAL, s, Q);
-        return dt_prof_report(c, d, nwg, s);
-    }
-    {
-        TimedLaunch tl(c, s);
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), LD::TOTAL, s, P);
-    }
-    HIP_TRY(c, hipGetLastError());
-    return BUSCA_OK;
-}
-
-// ---- tiled (layer-wise) path ---------------------------------------------------------------------------------------
-template <int PREC, int D, int EPI, int RT>
-static int dtl_gemm_rt(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblocks) {
-    constexpr int BM = 32 * RT;
-    const size_t lds = (size_t)(BM + D) * 128 + 2 * 4 * BM * sizeof(float);
-    auto kern = dtl_gemm_kernel<PREC, D, EPI, RT>;
-    { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
-    TimedLaunch tl(c, s);
-    hipLaunchKernelGGL(kern, dim3((a.M + BM - 1) / BM, ncolblocks), dim3(512), lds, s, a);
-    return BUSCA_OK;
-}
-
-// 64-row tiles (two workgroups per CU: one's epilogue traffic overlaps the other's MFMA phase) for the epilogue-heavy GEMMs
-// when the tile fits twice into the LDS (d <= 512); BUSCA_DTL_RT=4 / 2 forces either geometry.
-template <int PREC, int D, int EPI>
-static int dtl_gemm(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolblocks) {
-    const int rt_env = c->opt.dtl_rt, rt_mask = c->opt.dtl_rt_mask;      // bit EPI of the mask = 64-row tiles for that GEMM kind
-    // default: 64-row tiles only when 128-row tiles would fill less than half the chip (fewer than 128 workgroups) - measured
-    // 128 lost x 32 proposals x d512 (79 row blocks): 64-row tiles for the single-column-block GEMMs 0.93 -> 0.86 ms (f16), f32
-    // 3.38 -> 2.9 ms; from 158 row blocks on (two such steps in flight) 64-row tiles LOSE 5-10 %, and at >= 256 workgroups
-    // the two geometries are within +-8 % per GEMM kind with no consistent winner (512 x 64 x d512: 4.25 ms vs 4.6 ms)
-    const bool underfilled = (long)((a.M + 127) / 128) * ncolblocks < 128;
-    const bool small = rt_mask >= 0 ? ((rt_mask >> EPI) & 1) != 0 : (rt_env == 2 || (rt_env == 0 && underfilled));
-    if (small && (size_t)(64 + D) * 128 + 2 * 4 * 64 * 4 <= 80 * 1024) return dtl_gemm_rt<PREC, D, EPI, 2>(c, s, a, ncolblocks);
-    return dtl_gemm_rt<PREC, D, EPI, 4>(c, s, a, ncolblocks);
-}
-
-template <int PREC, int HD, int MT>
-static int dtl_attention(busca_ctx* c, hipStream_t s, const void* qkv, void* O, int B, int T, int D, int NH, float* att) {
-    constexpr int ES = Prec<PREC>::ES, TPK = Prec<PREC>::CHUNK * Prec<PREC>::nchunks(MT);
-    const size_t lds = (size_t)16 * MT * (HD * ES + 16) + (size_t)HD * (TPK * ES + 16);
-    if (lds > 160 * 1024) return fail(c, BUSCA_EINVAL, "tiled attention: %d tokens x head dim %d do not fit the LDS in this precision", T, HD);
-    auto kern = dtl_attention_kernel<PREC, HD, MT>;
-    { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
-    TimedLaunch tl(c, s);
-    hipLaunchKernelGGL(kern, dim3(B, NH), dim3(256), lds, s, qkv, O, T, D, NH, att);
-    return BUSCA_OK;
-}
-
-template <int PREC, int HD>
-static int dtl_attention_mt(busca_ctx* c, hipStream_t s, int MT, const void* qkv, void* O, int B, int T, int D, int NH, float* att) {
-    switch (MT) {
-        case 1: return dtl_attention<PREC, HD, 1>(c, s, qkv, O, B, T, D, NH, att);
-        case 2: return dtl_attention<PREC, HD, 2>(c, s, qkv, O, B, T, D, NH, att);
-        case 3: return dtl_attention<PREC, HD, 3>(c, s, qkv, O, B, T, D, NH, att);
-        case 4: return dtl_attention<PREC, HD, 4>(c, s, qkv, O, B, T, D, NH, att);
-        case 5: return dtl_attention<PREC, HD, 5>(c, s, qkv, O, B, T, D, NH, att);
-        case 6: return dtl_attention<PREC, HD, 6>(c, s, qkv, O, B, T, D, NH, att);
-        case 7: return dtl_attention<PREC, HD, 7>(c, s, qkv, O, B, T, D, NH, att);
-        case 8: return dtl_attention<PREC, HD, 8>(c, s, qkv, O, B, T, D, NH, att);
-        case 9: return dtl_attention<PREC, HD, 9>(c, s, qkv, O, B, T, D, NH, att);
-    }
-    return fail(c, BUSCA_EINVAL, "tiled attention supports at most 144 tokens per track (got %d)", T);
-}
-
-// head width HD = d / nhead in {16, 32, 64, 128} (nhead 4 at d = 64 / 256 / 512 are 16 / 64 / 128)
-template <int PREC>
-static int dtl_attention_hd(busca_ctx* c, hipStream_t s, int MT, const void* qkv, void* O, int B, int T, int D, int NH, float* att) {
-    switch (D / NH) {
-        case 16: return dtl_attention_mt<PREC, 16>(c, s, MT, qkv, O, B, T, D, NH, att);
-        case 32: return dtl_attention_mt<PREC, 32>(c, s, MT, qkv, O, B, T, D, NH, att);
-        case 64: return dtl_attention_mt<PREC, 64>(c, s, MT, qkv, O, B, T, D, NH, att);
-        case 128: return dtl_attention_mt<PREC, 128>(c, s, MT, qkv, O, B, T, D, NH, att);
-    }
-    return fail(c, BUSCA_EINVAL, "tiled attention: head width %d not built (16, 32, 64, 128)", D / NH);
-}
-
-// QKV projection + attention of a (track, head) in one kernel (dtl_qkv_attn_kernel): built for the shipped head geometry (four heads: d = 512 /
-// 128-wide, d = 256 / 64-wide) and the token counts the one-kernel path cannot hold.  Returns false when this shape is not built.
-template <int PREC, int D, int HD, int MT>
-static int dtl_qkv_attn_launch(busca_ctx* c, hipStream_t s, const DTLQkvAttnArgs& a, int B) {
-    constexpr int ES = Prec<PREC>::ES, CH = Prec<PREC>::CHUNK, TP = 16 * MT, TPK = CH * Prec<PREC>::nchunks(MT);
-    constexpr size_t ga = (size_t)TP * ((D / 2) * ES + 16), at = (size_t)2 * TP * (HD * ES + 16) + (size_t)HD * (TPK * ES + 16);
-    constexpr size_t lds = ga > at ? ga : at;
-    static_assert(lds <= 160 * 1024, "fused QKV + attention: LDS plan");
-    auto kern = dtl_qkv_attn_kernel<PREC, D, HD, MT>;
-    { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
-    TimedLaunch tl(c, s);
-    hipLaunchKernelGGL(kern, dim3(B, a.NH), dim3(4 * HD), lds, s, a);
-    return BUSCA_OK;
-}
-template <int PREC, int D>
-static bool dtl_qkv_attn(busca_ctx* c, hipStream_t s, const DTLQkvAttnArgs& a, int B, int MT, int* rc) {
-    constexpr int HD = D / 4;
-    *rc = BUSCA_OK;
-    if (D < 256 || a.NH != 4) return false;
-#define QA(M_) case M_: *rc = dtl_qkv_attn_launch<PREC, (D >= 256 ? D : 256), (D >= 256 ? HD : 64), M_>(c, s, a, B); return true
-    if constexpr (PREC == 1) { switch (MT) { QA(5); QA(6); QA(7); QA(8); QA(9); } }
-    else { switch (MT) { QA(3); QA(4); QA(5); } }
-#undef QA
-    return false;
-}
-
 // Workspace of the layer-wise path for M rows (bytes).  Grown outside the forward by busca_dt_reserve; a forward that finds
 // it too small grows it itself (one stream synchronisation + hipMalloc, first call of a larger shape only).
-static size_t dtl_ws_bytes(size_t M, int D, int FF, size_t es) {
+size_t dtl_ws_bytes(size_t M, int D, int FF, size_t es) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     return al(M * D * 4) + al(M * D * 2) + al(M * 3 * D * es) + al(M * D * es) + al(M * FF * es) + al(M * 3 * 4);
 }
 
-static int dtl_ws_ensure(busca_ctx* c, size_t need, hipStream_t s) {
+int dtl_ws_ensure(busca_ctx* c, size_t need, hipStream_t s) {
     DTState& S = c->dt;
     if (S.ws_bytes >= need) return BUSCA_OK;
     if (S.ws) { HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(S.ws)); S.ws = nullptr; S.ws_bytes = 0; }
@@ -729,92 +376,10 @@ static int dtl_ws_ensure(busca_ctx* c, size_t need, hipStream_t s) {
     return BUSCA_OK;
 }
 
-template <int PREC, int D>
-static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
-    DTState& S = c->dt;
-    constexpr size_t ES = Prec<PREC>::ES;
-    const int T = K.T, B = K.B, L = K.L, P = K.P, FF = S.cfg.ff, NH = S.cfg.nhead, E = 512;
-    const int MT = (T + 15) / 16;
-    if (MT > 9) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most 144 tokens per track (T=%d)", T);
-    if (P + K.nspec > 128) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most %d proposals (P=%d)", 128 - K.nspec, P);
-    const size_t M = (size_t)B * T;
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    { int rc = dtl_ws_ensure(c, dtl_ws_bytes(M, D, FF, ES), s); if (rc) return rc; }
-    char* p = (char*)S.ws;
-    float* X = (float*)p; p += al(M * D * 4);
-    _Float16* Xh = (_Float16*)p; p += al(M * D * 2);
-    char* QKV = p; p += al(M * 3 * D * ES);
-    char* O = p; p += al(M * D * ES);
-    char* H = p; p += al(M * FF * ES);
-    int* ids = (int*)p;
-    const void* Xop = PREC == 0 ? (const void*)X : (const void*)Xh;      // GEMM operand copy of the residual stream
-    { TimedLaunch tl(c, s); hipLaunchKernelGGL(dt_bucket_ids_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, K.mem_ltrb, K.can_ltrb, B, L, P, K.fake_f64, K.can_pos, K.nspec, K.sep_can, ids); }
-    DTLArgs a{};
-    a.M = (int)M; a.L = L; a.P = P; a.T = T; a.E = E; a.can_pos = K.can_pos; a.X = X; a.Xh = Xh; a.act = K.act;
-    a.qscale = 1.0f / sqrtf((float)(D / NH));
-    // embed + assembly + encoding
-    a.W = S.tw.w_embed; a.K = E; a.bias = K.b_embed; a.mem_feat = K.mem_feat; a.can_feat = K.can_feat; a.ids = ids;
-    a.lut_xy = K.lut_xy; a.lut_sz = K.lut_sz; a.lut_t = K.lut_t; a.lut_c = K.lut_c;
-    a.tok_sep = K.tok_sep; a.tok_non = K.tok_non; a.tok_bad = K.tok_bad;
-    { int rc = dtl_gemm<PREC, D, DTL_EPI_EMBED>(c, s, a, 1); if (rc) return rc; }
-    for (int l = 0; l < K.nlayers; ++l) {
-        const DTLayerW& W = K.layer[l];
-        float* att = K.att ? K.att + (size_t)l * B * NH * T * T : nullptr;
-        bool fused_attn = false;
-        if (c->opt.dtl_attn != 0) {
-            DTLQkvAttnArgs q{};
-            q.Xop = Xop; q.w_in = W.w_in; q.b_in = W.b_in; q.O = O; q.att = att; q.T = T; q.NH = NH; q.qscale = a.qscale;
-            int rc = BUSCA_OK;
-            fused_attn = dtl_qkv_attn<PREC, D>(c, s, q, B, MT, &rc);
-            if (rc) return rc;
-        }
-        if (!fused_attn) {
-            a.A = Xop; a.lda = D; a.W = S.tw.w_in[l]; a.K = D; a.bias = W.b_in; a.out16 = QKV; a.ldo = 3 * D;
-            {
-                int rc = dtl_gemm<PREC, D, DTL_EPI_QKV>(c, s, a, 3);
-                if (rc) return rc;
-            }
-            { int rc = dtl_attention_hd<PREC>(c, s, MT, QKV, O, B, T, D, NH, att); if (rc) return rc; }
-        }
-        const int ffn_mode = D >= 256 ? c->opt.dtl_ffn : 0;   // 2: out-proj + norm1 + feed-forward + norm2 in one kernel; 1: feed-forward block only; 0: layer-wise GEMMs
-        if (ffn_mode != 2) {
-            a.A = O; a.lda = D; a.W = S.tw.w_out[l]; a.K = D; a.bias = W.b_out; a.gamma = W.g1; a.beta = W.be1;
-            { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
-        }
-        if (ffn_mode != 0) {
-            // the row-local half of the layer in one kernel: x1 (mode 2) and H never reach HBM (dtl_ffn_kernel)
-            DTLFfnArgs f{};
-            f.Xop = Xop; f.Oop = O; f.X = X; f.Xh = Xh; f.w_out = W.w_out; f.w1 = W.w1; f.w2 = W.w2; f.b_out = W.b_out; f.g1 = W.g1; f.be1 = W.be1;
-            f.b1 = W.b1; f.b2 = W.b2; f.gamma = W.g2; f.beta = W.be2; f.M = (int)M; f.FF = FF; f.act = K.act;
-            constexpr int DK = D >= 256 ? D : 256;
-            constexpr int BMF = DTLFfnGeom<PREC, DK>::BM;
-            constexpr size_t flds = DTLFfnGeom<PREC, DK>::LDS;
-            TimedLaunch tl(c, s);
-            if (ffn_mode == 2) {
-                auto kern = dtl_ffn_kernel<PREC, DK, true>;
-                { int rc = ensure_lds(c, (const void*)kern, flds); if (rc) return rc; }
-                hipLaunchKernelGGL(kern, dim3((unsigned)((M + BMF - 1) / BMF)), dim3(64 * DTLFfnGeom<PREC, DK>::NWV), flds, s, f);
-            } else {
-                auto kern = dtl_ffn_kernel<PREC, DK, false>;
-                { int rc = ensure_lds(c, (const void*)kern, flds); if (rc) return rc; }
-                hipLaunchKernelGGL(kern, dim3((unsigned)((M + BMF - 1) / BMF)), dim3(64 * DTLFfnGeom<PREC, DK>::NWV), flds, s, f);
-            }
-            continue;
-        }
-        a.A = Xop; a.lda = D; a.W = S.tw.w1[l]; a.K = D; a.bias = W.b1; a.out16 = H; a.ldo = FF;
-        {
-            int rc = dtl_gemm<PREC, D, DTL_EPI_FFN1>(c, s, a, FF / D);
-            if (rc) return rc;
-        }
-        a.A = H; a.lda = FF; a.W = S.tw.w2[l]; a.K = FF; a.bias = W.b2; a.gamma = W.g2; a.beta = W.be2;
-        { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
-    }
-    if (K.hidden) HIP_TRY(c, hipMemcpyAsync(K.hidden, X, M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-    { TimedLaunch tl(c, s);
-      hipLaunchKernelGGL((dtl_decoder_kernel<D>), dim3(B), dim3(256), 0, s, (const float*)X, T, L, P, K.can_pos, K.nspec, K.dec_g, K.dec_b, K.dec_w, K.dec_bias,
-                         K.logits, K.probs, K.argmax); }
-    HIP_TRY(c, hipGetLastError());
-    return BUSCA_OK;
+void dt_bucket_ids_launch(busca_ctx* c, hipStream_t s, const float* mem_ltrb, const float* can_ltrb, int B, int L, int P, int fake_f64, int can_pos, int nspec, int sep_can, int* ids) {
+    const size_t n = (size_t)B * (L + 2 * (P + nspec));
+    TimedLaunch tl(c, s);
+    hipLaunchKernelGGL(dt_bucket_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mem_ltrb, can_ltrb, B, L, P, fake_f64, can_pos, nspec, sep_can, ids);
 }
 
 extern "C" int busca_dt_reserve(busca_ctx* c, int32_t B, int32_t L, int32_t P, void* stream) {
@@ -856,36 +421,20 @@ static int dt_forward_impl(busca_ctx* c, const float* mem_feat, const float* can
     const int ntrk_env = c->opt.dt_ntrk;
     const long r1 = (B + 255) / 256, r2 = (B + 511) / 512;
     const bool two = ntrk_env == 2 || (ntrk_env == 0 && B > 256 && r2 * 188 <= r1 * 100);
-#define DT_CASE2(M, DD, NCH) if (fused_ok && two && prec == 1 && MT == M && d == DD) return dt_launch<1, M, DD, 2 * DD, NCH, 2>(c, K, s)
-    DT_CASE2(3, 256, 1); DT_CASE2(2, 256, 1);        // d = 512: the parked f32 residual does not fit the LDS plan
-#undef DT_CASE2
-#define DT_CASE(PR, M, DD, NCH) if (fused_ok && prec == PR && MT == M && d == DD) return dt_launch<PR, M, DD, 2 * DD, NCH>(c, K, s)
-    DT_CASE(0, 1, 64, 1); DT_CASE(0, 1, 256, 1); DT_CASE(0, 1, 512, 1); DT_CASE(1, 1, 64, 1); DT_CASE(1, 1, 256, 1); DT_CASE(1, 1, 512, 1);
-    DT_CASE(0, 2, 64, 1); DT_CASE(0, 3, 64, 1); DT_CASE(0, 4, 64, 1);
-    DT_CASE(0, 2, 256, 1); DT_CASE(0, 3, 256, 1);
-    DT_CASE(0, 2, 512, 2);
-    DT_CASE(1, 2, 64, 1); DT_CASE(1, 3, 64, 1); DT_CASE(1, 4, 64, 1);
-    DT_CASE(1, 2, 256, 1); DT_CASE(1, 3, 256, 1); DT_CASE(1, 4, 256, 1); DT_CASE(1, 5, 256, 1);
-    DT_CASE(1, 2, 512, 1); DT_CASE(1, 3, 512, 1); DT_CASE(1, 4, 512, 2);
-    // split-fp16 (float32-equivalent) flavour: the f32 kernel's shapes
-    DT_CASE(2, 1, 64, 1); DT_CASE(2, 1, 256, 1); DT_CASE(2, 1, 512, 1); DT_CASE(2, 2, 64, 1); DT_CASE(2, 3, 64, 1); DT_CASE(2, 4, 64, 1);
-    DT_CASE(2, 2, 256, 1); DT_CASE(2, 3, 256, 1); DT_CASE(2, 2, 512, 2);
-#undef DT_CASE
-    // shapes beyond the fused kernel's on-chip plan: layer-wise tiled path, same arithmetic type
-    if (prec == BUSCA_PREC_F16) {       // (x3 beyond the fused kernel's shapes: the exact f32 layer-wise path)
-        if (d == 64) return dt_forward_tiled<1, 64>(c, K, s);
-        if (d == 256) return dt_forward_tiled<1, 256>(c, K, s);
-        if (d == 512) return dt_forward_tiled<1, 512>(c, K, s);
-    } else {
-        if (prec == BUSCA_PREC_F16X3) {      // the f32 packing of the matrices (proto32)
-            K.w_embed = c->dt.proto32.w_embed;
-            for (int l = 0; l < K.nlayers; ++l) { K.layer[l].w_in = c->dt.proto32.layer[l].w_in; K.layer[l].w_out = c->dt.proto32.layer[l].w_out; K.layer[l].w1 = c->dt.proto32.layer[l].w1; K.layer[l].w2 = c->dt.proto32.layer[l].w2; }
-        }
-        if (d == 64) return dt_forward_tiled<0, 64>(c, K, s);
-        if (d == 256) return dt_forward_tiled<0, 256>(c, K, s);
-        if (d == 512) return dt_forward_tiled<0, 512>(c, K, s);
+    if (fused_ok) {
+        int rc = BUSCA_ENOKERNEL;
+        if (prec == BUSCA_PREC_F32) rc = dt_fused_f32(c, K, MT, d, s);
+        else if (prec == BUSCA_PREC_F16) rc = dt_fused_f16(c, K, MT, d, two, s);
+        else rc = dt_fused_x3(c, K, MT, d, s);
+        if (rc != BUSCA_ENOKERNEL) return rc;
     }
-    return fail(c, BUSCA_EINVAL, "no Decision-Transformer kernel for T=%d (tiles %d), d=%d", K.T, MT, d);
+    // shapes beyond the fused kernel's on-chip plan: layer-wise tiled path, same arithmetic type (x3: the exact f32 layer-wise path on the f32 packing, proto32)
+    if (prec == BUSCA_PREC_F16) return dt_tiled_f16(c, K, d, s);
+    if (prec == BUSCA_PREC_F16X3) {
+        K.w_embed = c->dt.proto32.w_embed;
+        for (int l = 0; l < K.nlayers; ++l) { K.layer[l].w_in = c->dt.proto32.layer[l].w_in; K.layer[l].w_out = c->dt.proto32.layer[l].w_out; K.layer[l].w1 = c->dt.proto32.layer[l].w1; K.layer[l].w2 = c->dt.proto32.layer[l].w2; }
+    }
+    return dt_tiled_f32(c, K, d, s);
 }
 
 extern "C" int busca_dt_forward(busca_ctx* c, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
@@ -910,11 +459,9 @@ extern "C" int busca_dt_bucket_ids(busca_ctx* c, const float* mem_ltrb, const fl
     if (B == 0) return BUSCA_OK;
     const int fake64 = c->dt.loaded ? c->dt.proto.fake_f64 : 1;
     const int can_pos = c->dt.loaded ? c->dt.proto.can_pos : 1, nspec = c->dt.loaded ? c->dt.proto.nspec : 2, sep_can = c->dt.loaded ? c->dt.proto.sep_can : 0;
-    const int n = B * (L + 2 * (P + nspec));
-    hipLaunchKernelGGL(dt_bucket_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, mem_ltrb, can_ltrb, B, L, P, fake64, can_pos, nspec, sep_can, ids);
+    dt_bucket_ids_launch(c, (hipStream_t)stream, mem_ltrb, can_ltrb, B, L, P, fake64, can_pos, nspec, sep_can, ids);
     HIP_TRY(c, hipGetLastError());
     return BUSCA_OK;
 }
 
 #include "capi_geometry.hip.inc"
-#include "capi_reid.hip.inc"

@@ -405,7 +405,7 @@ class BUSCA:
         order = np.full((B, P), -1, np.int64)
         if N > 0:
             d = np.ascontiguousarray(np.asarray(dists_matrix, dtype=np.float64).reshape(B, N))
-            order = geometry.topk_rows(self._ctx, d, P).cpu().numpy().astype(np.int64)
+            order = geometry.topk_rows_host(self._ctx, d, P).astype(np.int64)
         miss = tracking.missing_candidate_bbox(flavour="ltwh", pinned_numpy=self.pinned_numpy).astype(np.float64)
         can_ref = [[None] * P for _ in range(B)]
         can_box = np.empty((B, P, 4), np.float64)

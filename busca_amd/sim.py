@@ -71,16 +71,23 @@ class SimScene:
         Kalman candidates) exactly as a tracker hands them to associate_embeddings."""
         return self.crop_inputs(*self.next_frame(), n_lost)
 
-    def crop_inputs(self, frame, boxes, n_lost):
+    def crop_inputs(self, frame, boxes, n_lost, per_detection=False):
         """The tracker-side half of step_inputs for a frame already produced (next_frame): the two get_image_crops calls of an update - detections,
         Kalman boxes of the lost tracks - and the objects built from them."""
         tlbr = boxes.copy()
         tlbr[:, 2:] += tlbr[:, :2]
         det_idx = np.arange(n_lost, self.n)
         t0 = time.perf_counter()
-        with self.model.frame(frame):                # one upload for both calls (explicit scope: an integrated adapter's `with model.frame(img):` around update)
-            det_crops = self.model.get_image_crops(frame, tlbr[det_idx], normalize=False)
-            kal_crops = self.model.get_image_crops(frame, tlbr[:n_lost], normalize=False)
+        if per_detection:
+            # the call pattern of the UNCHANGED StrongSORT / GHOST adapters (deep_sort/tracker.py:126,273,291): one get_image_crops per detection / per
+            # Kalman box, no frame scope - every call reads the live host frame
+            det_crops = [self.model.get_image_crops(frame, tlbr[i:i + 1], normalize=False)[0] for i in det_idx]
+            kal_crops = [self.model.get_image_crops(frame, tlbr[i:i + 1], normalize=False)[0] for i in range(n_lost)]
+        else:
+            with self.model.frame(frame):            # one upload for both calls (explicit scope: an integrated adapter's `with model.frame(img):` around update)
+                det_crops = self.model.get_image_crops(frame, tlbr[det_idx], normalize=False)
+                kal_crops = self.model.get_image_crops(frame, tlbr[:n_lost], normalize=False)
+        self.last_crop_call_count = (len(det_idx) + n_lost) if per_detection else 2
         # the crops are in HBM when the tracker's stream is done; their host copy (lazy mode: a side stream into pinned memory) keeps flowing
         # under whatever follows and is only waited for by a host read of the pixels
         torch.cuda.current_stream().synchronize()

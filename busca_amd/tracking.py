@@ -42,8 +42,7 @@ def center_distance(atracks, btracks, weight_size=False, ctx=None):
         return np.zeros((len(atracks), len(btracks)), dtype=np.float64)
     ctx = ctx or geometry.default_context()
     mode = _lib.PAIR_CENTER_WEIGHTED if weight_size else _lib.PAIR_CENTER
-    out = geometry.pairwise(ctx, a, b, mode)
-    return out.cpu().numpy()
+    return geometry.pairwise_host(ctx, a, b, mode)
 
 
 def iou_distance(atlbrs, btlbrs, det_scores=None, ctx=None):
@@ -53,7 +52,7 @@ def iou_distance(atlbrs, btlbrs, det_scores=None, ctx=None):
     if len(a) == 0 or len(b) == 0:
         return np.zeros((len(a), len(b)), dtype=np.float64)
     ctx = ctx or geometry.default_context()
-    return geometry.pairwise(ctx, a, b, _lib.PAIR_IOU_COST, scores_b=det_scores).cpu().numpy()
+    return geometry.pairwise_host(ctx, a, b, _lib.PAIR_IOU_COST, scores_b=det_scores)
 
 TRACKED = 1     # TrackState.Tracked (adapters/*/mot_online/basetrack.py:5-9)
 

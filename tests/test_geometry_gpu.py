@@ -47,6 +47,10 @@ def test_pairwise_bit_exact(ctx, nA, nB, mode):
     got = got.cpu().numpy()
     assert got.shape == ref.shape
     assert np.array_equal(got, ref, equal_nan=True)
+    # the host-table route of the per-frame tracker calls (boxes in, matrix out through one pinned table; tracking.center_distance / iou_distance)
+    hm = {"center": _lib.PAIR_CENTER, "center_w": _lib.PAIR_CENTER_WEIGHTED, "iou": _lib.PAIR_IOU}.get(mode, _lib.PAIR_IOU_COST)
+    host = G.pairwise_host(ctx, a, b, hm, scores_b=sc if mode == "fuse" else None)
+    assert isinstance(host, np.ndarray) and host.shape == ref.shape and np.array_equal(host, ref, equal_nan=True)
 
 
 def test_center_distance_matches_scipy(ctx):
@@ -59,8 +63,11 @@ def test_center_distance_matches_scipy(ctx):
     assert np.array_equal(og.center_distance(a, b), cdist(ac, bc, metric="euclidean"))
 
 
-@pytest.mark.parametrize("B,N,P", [(32, 150, 16), (128, 150, 32), (3, 4, 16), (7, 0, 5), (64, 1000, 64), (1, 1, 1)])
+@pytest.mark.parametrize("B,N,P", [(32, 150, 16), (128, 150, 32), (3, 4, 16), (7, 0, 5), (64, 1000, 64), (1, 1, 1),
+                                   (5, 255, 32), (5, 256, 300), (5, 257, 7), (9, 511, 64), (9, 512, 64), (4, 1024, 33), (6, 1100, 40)])
 def test_topk_rows_bit_exact(ctx, B, N, P):
+    """Every flavour of the top-P kernel (rank kernel with 1 / 2 / 4 keys per thread, odd and even rows, the round-by-round kernel beyond 1 024 columns):
+    exact ties, +-0.0, inf, NaN, all-equal rows, more slots than columns."""
     from busca_amd import geometry as G
     from oracle import geometry as og
     d = synth.uniform(B + N + P, "d", (B, N), 0, 500).astype(np.float64)
@@ -69,9 +76,14 @@ def test_topk_rows_bit_exact(ctx, B, N, P):
         d[0, 3] = np.inf
         d[0, 4] = -0.0
         d[0, 6] = 0.0
+        d[1, 7] = np.nan           # np.argsort: NaN last
+        d[1, N - 1] = np.nan
+        d[2, :] = 3.25             # a whole row of ties: indices in order
     got = G.topk_rows(ctx, d, P).cpu().numpy()
     ref = og.topk_rows(d, P)
     assert np.array_equal(got, ref)
+    if B and N:                  # the host-table route of associate_embeddings (pinned rows in, pinned indices out): same kernel, same answer
+        assert np.array_equal(G.topk_rows_host(ctx, d, P), ref)
 
 
 def _frame(seed, H, W):
@@ -109,6 +121,41 @@ def test_crop_gather_bit_exact(ctx):
     gn = f16.cpu().numpy()
     assert np.array_equal(gn[..., :3], ref_n)
     assert (gn[..., 3] == 0).all()
+
+
+def test_crops_of_a_few_boxes_upload_only_their_part_of_the_frame(ctx):
+    """The unchanged StrongSORT adapter calls get_image_crops once per detection (deep_sort/tracker.py:126,273,291).  Outside a frame scope the host frame is
+    read live on every call, but only the sub-frame spanned by the clipped boxes is uploaded (geometry._frame_for_rects): the crops must be the oracle's bytes
+    for boxes inside the frame, across each edge, across two edges, wholly outside, of zero extent - alone and in small groups - and equal to what the
+    whole-frame route (a frame that is already a device tensor) cuts."""
+    from busca_amd import geometry as G
+    from oracle import geometry as og
+    H, W = 540, 960
+    fr = _frame(7, H, W)
+    dev_fr = torch.from_numpy(fr).cuda()
+    boxes = np.array([
+        [100.3, 50.2, 180.9, 300.7], [-20.5, -30.0, 60.2, 200.0], [900.0, 400.0, 1000.0, 600.0], [930.2, -12.0, 975.5, 90.0], [-5.0, 500.0, 40.0, 560.0],
+        [5.5, 5.5, 6.2, 6.1], [2000.0, 2000.0, 2100.0, 2200.0], [-300.0, 100.0, -200.0, 300.0], [50.0, 60.0, 50.0, 60.0], [400.0, 100.0, 520.0, 439.5],
+    ], dtype=np.float64)
+    seen_sub = 0
+    groups = [[i] for i in range(len(boxes))] + [[0, 9], [1, 4], [2, 3, 6], [6, 7], [5, 8, 0]]
+    for gsel in groups:
+        bx = boxes[gsel]
+        t, shifted = G._frame_for_rects(ctx, fr, __import__("busca_amd.tracking", fromlist=["box_extents"]).box_extents(bx), torch.device("cuda", ctx.device))
+        seen_sub += int(tuple(t.shape[:2]) != (H, W))
+        got = G.crop_gather(ctx, fr, bx, want_u8=True)[0].cpu().numpy()
+        full = G.crop_gather(ctx, dev_fr, bx, want_u8=True)[0].cpu().numpy()
+        for k, i in enumerate(gsel):
+            assert np.array_equal(got[k], og.get_bbox_crop(fr, boxes[i])), (gsel, i)
+        assert np.array_equal(got, full), gsel
+        sized = G.crop_gather_sized(ctx, fr, bx, 64, 192).cpu().numpy()
+        for k, i in enumerate(gsel):
+            assert np.array_equal(sized[k], og.get_bbox_crop(fr, boxes[i], output_size=(64, 192))), (gsel, i)
+    assert seen_sub >= 10                      # the sub-frame route really ran (boxes wholly outside / of zero extent fall back to the whole frame)
+    fr2 = fr.copy()
+    fr2[60:200, 110:170] = 255 - fr2[60:200, 110:170]              # the live array changed between two calls: the second call must see it
+    assert not np.array_equal(G.crop_gather(ctx, fr2, boxes[:1], want_u8=True)[0].cpu().numpy(), G.crop_gather(ctx, fr, boxes[:1], want_u8=True)[0].cpu().numpy())
+    assert np.array_equal(G.crop_gather(ctx, fr2, boxes[:1], want_u8=True)[0].cpu().numpy()[0], og.get_bbox_crop(fr2, boxes[0]))
 
 
 @pytest.mark.parametrize("out_wh", [(64, 192), (96, 96), (128, 256), (50, 37), (256, 768)])

@@ -10,7 +10,7 @@ from busca_amd.sim import SimScene
 from busca_amd.tracking import center_distance
 
 
-def run(lost=32, n_obj=150, P=5, d=512, precision="x3", frames=30, verbose=True, device_only_crops=False, reid_precision="x3"):
+def run(lost=32, n_obj=150, P=5, d=512, precision="x3", frames=30, verbose=True, device_only_crops=False, reid_precision="x3", per_detection_crops=False):
     """Defaults = the library's defaults (busca_amd.network.BUSCA: float32-equivalent x3 Decision Transformer + x3 ReID)."""
     args = types.SimpleNamespace(reid_precision=reid_precision, num_layer=4, nhead=4, dim_embedding=512, trans_dim=d, ff_size=2 * d, activation="gelu", dropout_p=0.1,
                                  input_flavour="MEM-SEP-CAN-BAD", output_flavour="CAN", encode_separator_as_reference=True,
@@ -24,7 +24,7 @@ def run(lost=32, n_obj=150, P=5, d=512, precision="x3", frames=30, verbose=True,
         frame, boxes = scene.next_frame()            # producing the synthetic frame is not part of the crop path
         torch.cuda.synchronize()
         a = time.perf_counter()
-        lost_t, dets, kal = scene.crop_inputs(frame, boxes, lost)
+        lost_t, dets, kal = scene.crop_inputs(frame, boxes, lost, per_detection=per_detection_crops)
         b = time.perf_counter()
         dists = center_distance(lost_t, dets)
         c = time.perf_counter()
@@ -40,7 +40,7 @@ def run(lost=32, n_obj=150, P=5, d=512, precision="x3", frames=30, verbose=True,
                max_assoc_latency_ms=float(np.max(t_assoc) * 1e3), p90_crop_ms=float(np.percentile(t_crop, 90) * 1e3),
                p50_crop_and_sim_objects_ms=float(np.percentile(t_sim, 50) * 1e3),
                busca_frames_per_s=float(1.0 / np.mean(np.array(t_assoc) + np.array(t_dist))),
-               device_resident_crops=model.last_gather[1] == 0, device_only_crops=device_only_crops)
+               device_resident_crops=model.last_gather[1] == 0, device_only_crops=device_only_crops, crop_calls_per_frame=scene.last_crop_call_count)
     if verbose:
         print(res)
     return res
