@@ -80,10 +80,11 @@ class StepBatcher:
             self.launches += 1
             torch.cuda.current_stream(dev).synchronize()
             out = m._dt.settle(out)             # a merged x3 launch that clipped an operand is run again in exact float32 before it is handed out
+            reid_overflow = m._reid.take_status()       # (one status word per context: every step of this flush is suspect when an x3 ReID pass overflowed)
             lo = 0
             for t in ts:
                 hi = lo + t._job["B"]
                 part = {k: v[lo:hi] for k, v in out.items()}
-                t._value, t._done = m._assoc_finish(t._job, part), True
+                t._value, t._done = m._assoc_finish(t._job, part, reid_overflow), True
                 lo = hi
                 self.steps += 1

@@ -52,12 +52,7 @@ extern "C" int busca_set_option(busca_ctx* c, const char* name, int32_t value) {
     if (n.rfind("reid_", 0) == 0) return reid_set_option(c, name, value);
     if (n == "dt_ntrk") o.dt_ntrk = value;
     else if (n == "dt_split") o.dt_split = value;
-    else if (n == "dt_prof") o.dt_prof = value;
     else if (n == "dt_tiled") o.dt_tiled = value;
-    else if (n == "dtl_rt") o.dtl_rt = value;
-    else if (n == "dtl_rt_mask") o.dtl_rt_mask = value;
-    else if (n == "dtl_ffn") o.dtl_ffn = value;
-    else if (n == "dtl_attn") o.dtl_attn = value;
     else if (n == "crop_band") o.crop_band = value;
     else if (n == "dt_exact_f32") o.dt_exact_f32 = value != 0;
     else if (n == "dt_status") { if (c->dt.xerr) *c->dt.xerr = value; }      // 0 = the caller has read the status of its synchronised forward and dealt with it
@@ -75,10 +70,6 @@ extern "C" int busca_get_option(busca_ctx* c, const char* name, int32_t* value) 
     else if (n == "dt_status") *value = c->dt.xerr ? *c->dt.xerr : 0;       // 0 ok, 1 a split launch lost a partner, 2 an x3 forward clipped an operand; valid once the forward's stream is
                                                                             // synchronised; cleared by busca_set_option("dt_status", 0) (an uncleared status is also returned by the next forward)
     else if (n == "dt_tiled") *value = o.dt_tiled;
-    else if (n == "dtl_rt") *value = o.dtl_rt;
-    else if (n == "dtl_rt_mask") *value = o.dtl_rt_mask;
-    else if (n == "dtl_ffn") *value = o.dtl_ffn;
-    else if (n == "dtl_attn") *value = o.dtl_attn;
     else if (n == "crop_band") *value = o.crop_band;
     else if (n == "dt_exact_f32") *value = o.dt_exact_f32;
     else if (n == "last_dt_grid") *value = o.last_dt_grid;

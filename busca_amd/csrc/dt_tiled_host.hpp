@@ -123,6 +123,7 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     a.W = S.tw.w_embed; a.K = E; a.bias = K.b_embed; a.mem_feat = K.mem_feat; a.can_feat = K.can_feat; a.ids = ids;
     a.lut_xy = K.lut_xy; a.lut_sz = K.lut_sz; a.lut_t = K.lut_t; a.lut_c = K.lut_c;
     a.tok_sep = K.tok_sep; a.tok_non = K.tok_non; a.tok_bad = K.tok_bad;
+    a.skip_x32 = (PREC == 1 && D >= 256 && c->opt.dtl_ffn == 2) ? 1 : 0;       // every layer then runs dtl_ffn_kernel<.., OUTPROJ>, which carries the stream in Xh
     { int rc = dtl_gemm<PREC, D, DTL_EPI_EMBED>(c, s, a, 1); if (rc) return rc; }
     for (int l = 0; l < K.nlayers; ++l) {
         const DTLayerW& W = K.layer[l];
@@ -153,6 +154,7 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
             DTLFfnArgs f{};
             f.Xop = Xop; f.Oop = O; f.X = X; f.Xh = Xh; f.w_out = W.w_out; f.w1 = W.w1; f.w2 = W.w2; f.b_out = W.b_out; f.g1 = W.g1; f.be1 = W.be1;
             f.b1 = W.b1; f.b2 = W.b2; f.gamma = W.g2; f.beta = W.be2; f.M = (int)M; f.FF = FF; f.act = K.act;
+            f.write_x32 = l == K.nlayers - 1;            // (f16 flavour: the float32 copy of the residual stream only where the decoder / `hidden` read it)
             constexpr int DK = D >= 256 ? D : 256;
             constexpr int BMF = DTLFfnGeom<PREC, DK>::BM;
             constexpr size_t flds = DTLFfnGeom<PREC, DK>::LDS;

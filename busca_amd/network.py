@@ -441,11 +441,15 @@ class BUSCA:
         can_feat = self._reid.forward(can_u8, zero_norm=can_zn, weights=can_w)
         return dict(B=B, N=N, K=K, P=P, L=L, order=order, n_avail=n_avail, reliable=reliable, mem_ltrb=mem_ltrb, can_ltrb=can_ltrb,
                     mem_feat_side=mem_feat_side, can_feat=can_feat, mem_inv=mem_inv, can_inv=can_inv, select=bool(select_highest_candidate),
+                    mem_in=(mem_u8, mem_zn, mem_w), can_in=(can_u8, can_zn, can_w),      # the two BatchNorm batches themselves: an x3 pass that overflowed is run again in f32
                     thresh=highest_candidate_minimum_thresh, keep=bool(keep_highest_value))
 
     def _assoc_features(self, job):
         """Join the side-stream ReID batch: (mem_feat [B,L,512], can_feat [B,P,512]), the two BN batches of network.py:192-193."""
         can_feat, mem_feat = self._reid_join(job["mem_feat_side"], job["can_feat"])
+        return self._assoc_slots(job, mem_feat, can_feat)
+
+    def _assoc_slots(self, job, mem_feat, can_feat):
         dev = mem_feat.device                  # features of the distinct crops -> the [B, L] / [B, P] slots they stand for
         if len(job["mem_inv"]) != mem_feat.shape[0] or (job["mem_inv"] != np.arange(len(job["mem_inv"]))).any():
             mem_feat = mem_feat[torch.from_numpy(job["mem_inv"]).to(dev)]
@@ -453,7 +457,22 @@ class BUSCA:
             can_feat = can_feat[torch.from_numpy(job["can_inv"]).to(dev)]
         return mem_feat.view(job["B"], job["L"], -1), can_feat.view(job["B"], job["P"], -1)
 
-    def _assoc_finish(self, job, out):
+    def _assoc_exact_reid(self, job):
+        """The two BatchNorm batches of `job` on the exact-f32 extractor (its own busca_ctx: a context holds ONE ReID weight set; created on first use) and the
+        Decision Transformer on those features - what `reid_precision="f32"` computes for the same step."""
+        if getattr(self, "_reid_exact", None) is None:
+            self._reid_exact = ReIDEncoderHIP(_lib.Context(self._device_index), self._sd, prefix=_REID_PREFIX, precision="f32")
+        self.reid_exact_reruns = getattr(self, "reid_exact_reruns", 0) + 1
+        (mu8, mzn, mw), (cu8, czn, cw) = job["mem_in"], job["can_in"]
+        mem_feat = self._reid_exact.forward(mu8, zero_norm=mzn, weights=mw)
+        can_feat = self._reid_exact.forward(cu8, zero_norm=czn, weights=cw)
+        mem_feat, can_feat = self._assoc_slots(job, mem_feat, can_feat)
+        self._ctx.set_option("dt_status", 0)            # (whatever the discarded forward on the invalid features left behind)
+        out = self._dt.forward(mem_feat, can_feat, job["mem_ltrb"], job["can_ltrb"], want_hidden=self.store_logits)
+        torch.cuda.current_stream(self._dev()).synchronize()
+        return out
+
+    def _assoc_finish(self, job, out, reid_overflow=None):
         """network.py:403-429: probabilities -> [B, N_det (+B)] matrix (one-hot / thresholded / raw) + reliability flags.
         `out`: dict(probs [B,P+2], argmax [B], hidden?) of this job's tracks."""
         B, N, K, P, L = job["B"], job["N"], job["K"], job["P"], job["L"]
@@ -463,6 +482,11 @@ class BUSCA:
             self.logits = out["hidden"][:, pos]
             self.mem_logits = out["hidden"][:, :L].mean(dim=1)
         probs = out["probs"].cpu().numpy().astype(np.float64)                 # (synchronises the forward's stream)
+        if reid_overflow is None:
+            reid_overflow = self._reid.take_status()
+        if reid_overflow:                       # an x3 ReID pass of this step staged an activation beyond the split-fp16 range: both batches again, exact f32
+            out = self._assoc_exact_reid(job)
+            probs = out["probs"].cpu().numpy().astype(np.float64)
         fixed = self._dt.settle(out)            # an x3 forward that clipped an operand is run again in exact float32: the tracker never gets a clipped step
         if fixed is not out:
             out = self._last = fixed

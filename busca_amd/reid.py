@@ -29,12 +29,9 @@ class ReIDEncoderHIP:
         self.precision = precision
         self._blob = weights.reid_blob(state_dict, prefix)
         if precision == "x3":
-            # the split-fp16 flavour clamps staged activations at |x| <= 1023.5; a checkpoint whose BatchNorm affines could exceed that must not be clipped silently
-            self.x3_activation_bound, where = weights.x3_activation_bound(state_dict, prefix)
-            if self.x3_activation_bound > weights.X3_OPERAND_LIMIT:
-                import warnings
-                warnings.warn("ReID checkpoint: activations of %s may reach %.0f, beyond the split-fp16 (x3) operand range of %.0f - that flavour would clip them; "
-                              "use reid_precision 'f32' (exact float32 MFMA) for this checkpoint" % (where, self.x3_activation_bound, weights.X3_OPERAND_LIMIT), RuntimeWarning)
+            # a HINT only (a loose static bound: 48 sigma, summed over a layer's bottlenecks): the kernels themselves report an operand that leaves the
+            # split-fp16 range at run time (`take_status`), and busca_amd.network re-runs such a batch on the exact-f32 extractor
+            self.x3_activation_bound, self.x3_activation_bound_where = weights.x3_activation_bound(state_dict, prefix)
         want = ctx.lib.busca_reid_blob_floats()
         assert self._blob.size == want, (self._blob.size, want)
         self._upload()
@@ -49,6 +46,17 @@ class ReIDEncoderHIP:
         owner = getattr(self.ctx, "reid_owner", None)
         if owner is None or owner() is not self:
             self._upload()
+
+    def take_status(self):
+        """Call once the streams of this extractor's forwards are SYNCHRONISED.  True: a split-fp16 (x3) forward since the last call staged an activation beyond
+        |x| = 1023.5 (`reid_status` 2, include/busca_hip.h) - its BatchNorm statistics, hence the features of that batch, are not finite / not valid, and the caller
+        must compute the batch again on an exact-f32 extractor (BUSCA._assoc_finish does).  The status is cleared.  Always False for the f32 / f16 flavours."""
+        if self.precision != "x3":
+            return False
+        st = self.ctx.get_option("reid_status")
+        if st:
+            self.ctx.set_option("reid_status", 0)
+        return st != 0
 
     def reserve(self, n, stream=None):
         """Size the workspace that forwards on `stream` (default: the current stream) use for batches of up to n crops NOW

@@ -54,16 +54,24 @@ const char* busca_last_error(const busca_ctx* ctx);
 int busca_version(void);
 /* The compiler flags this library was built with (busca_amd/build.py passes them in; bench.py records the string). */
 const char* busca_build_info(void);
-/* Developer options of one context (kernel-flavour selection for A/B runs and the tests that compare flavours).  Defaults are read
- * from the environment ONCE, at busca_ctx_create (BUSCA_DT_NTRK, BUSCA_DT_TILED, BUSCA_DTL_RT, BUSCA_DTL_RT_MASK);
- * no forward reads the environment.  Names: "dt_ntrk" (0 auto / 1 / 2 tracks per workgroup of the f16 fused kernel), "dt_tiled"
- * (1 = force the layer-wise path), "dtl_rt" (0 auto / 2 / 4), "dtl_rt_mask" (-1 off), "dtl_ffn" (2 = out-proj + norm1 + feed-forward + norm2 of the layer-wise path as one kernel, 1 = feed-forward block only, 0 = one kernel per GEMM; BUSCA_DTL_FFN), "dtl_attn" (1 = QKV projection + attention of a (track, head) as one kernel where built; BUSCA_DTL_ATTN), "crop_band" (1 = crops through the LDS-staged band kernel, 0 = one thread per output pixel; BUSCA_CROP_BAND), "dt_split" (token-split tail of the fused kernel: -1 = the tracks of a launch's last, partial round run one 16-token tile per workgroup where that pays (f32 / x3), 0 = never, 1 / 2 = every track that fits, one / two tracks per workgroup (tests); BUSCA_DT_SPLIT), "dt_prof" (debug phase stamps); busca_get_option also
- * answers "last_dt_grid" / "last_dt_ntrk" / "last_dt_split" (workgroups, tracks per workgroup and token-split tracks of the last fused launch).  Unknown name: BUSCA_EINVAL.
- * ReID schedule knobs of a LOADED extractor (they start from the BUSCA_REID_* environment at busca_reid_load_weights and can be changed between
- * forwards): "reid_gram", "reid_halo", "reid_fuse_c1", "reid_fuse_c1_layers", "reid_fuse_c1_small", "reid_fuse_ds_layers",
- * "reid_halo_min", "reid_halo_half", "reid_halo_wpx", "reid_halo_wpx_min", "reid_gram_min", "reid_direct_rows", "reid_stats2", "reid_kwave_blocks",
- * "reid_kwave_halo", "reid_kwave_nw", "reid_kwave_pt", "reid_pipe_min", "reid_pipe_half",
- * "reid_pipe_all", "reid_x3_merge_layers", "reid_x3_half", "reid_x3_gram", "reid_x3_gram_min", "reid_x3_merge_in", "reid_x3_merge_in_min", "reid_x3_fuse_c1", "reid_x3_fuse_c1_min", "reid_x3_narrow3", "reid_x3_row3", "reid_x3_ptail", "reid_x3_stem_halo", "reid_x3_stem_u8", "reid_x3_stem_pool" (meanings: DESIGN.md section 5).  Before weights are loaded: BUSCA_ENOWEIGHTS. */
+/* Options of one context.  Defaults are read from the environment ONCE, at busca_ctx_create (BUSCA_DT_NTRK, BUSCA_DT_TILED, BUSCA_DT_SPLIT, BUSCA_CROP_BAND);
+ * no forward reads the environment.  Unknown name: BUSCA_EINVAL.
+ *   "dt_ntrk"       0 auto / 1 / 2 tracks per workgroup of the f16 fused kernel (busca_amd.batcher pins it so that merged launches keep each step's flavour)
+ *   "dt_tiled"      1 = force the layer-wise Decision-Transformer path (tests)
+ *   "dt_split"      token-split tail of the fused kernel: -1 = the tracks of a launch's last, partial round run one 16-token tile per workgroup where that
+ *                   pays (f32 / x3), 0 = never, 1 / 2 = every track that fits, one / two tracks per workgroup (tests)
+ *   "dt_exact_f32"  1 = a context loaded with BUSCA_PREC_F16X3 runs its forwards in exact float32 on the f32 packing it keeps of the same weights (how the
+ *                   host re-runs a step whose x3 forward reported a clipped operand)
+ *   "dt_status"     get: 0 ok, 1 = a token-split launch lost a partner workgroup, 2 = a BUSCA_PREC_F16X3 forward had to clip an operand beyond |x| = 1023.5 -
+ *                   valid once the forward's stream is synchronised; set 0: the caller has dealt with it (an uncleared status is returned by the next forward)
+ *   "reid_status"   get: 0 ok, 2 = a BUSCA_PREC_F16X3 ReID forward since the last clear staged an activation beyond |x| = 1023.5 (its features are invalid:
+ *                   non-finite BatchNorm statistics; nothing is clipped silently) - valid once the forwards' streams are synchronised; set 0 clears
+ *   "crop_band"     1 = crops through the LDS-staged band kernel, 0 = one thread per output pixel (tests compare the two)
+ *   get only: "last_dt_grid" / "last_dt_ntrk" / "last_dt_split" (workgroups, tracks per workgroup, token-split tracks of the last fused launch).
+ * ReID schedule switches of a LOADED extractor that tests flip between two forwards (BUSCA_ENOWEIGHTS before weights are loaded): "reid_gram", "reid_halo",
+ * "reid_fuse_c1", "reid_x3_fuse_c1", "reid_x3_gram_min", "reid_x3_merge_in_min", "reid_x3_row3", "reid_x3_ptail", "reid_x3_stem_halo", "reid_x3_stem_u8",
+ * "reid_x3_stem_pool" (meanings: DESIGN.md section 5).  The remaining schedule thresholds are BUSCA_REID_* environment variables read by
+ * busca_reid_load_weights (A/B runs). */
 int busca_set_option(busca_ctx* ctx, const char* name, int32_t value);
 int busca_get_option(busca_ctx* ctx, const char* name, int32_t* value);
 
@@ -118,8 +126,9 @@ int busca_dt_load_weights(busca_ctx* ctx, const busca_dt_cfg* cfg, const float* 
  *   att      [nlayers,B,nhead,T,T] f32 per-head attention weights              (may be NULL)
  * One Decision-Transformer forward per context at a time (its layer-wise workspace and the exchange buffers of the token-split tail belong
  * to the context; forwards on ONE stream are ordered by the stream - use one context per concurrently running stream).  A forward of the
- * BUSCA_PREC_F16X3 flavour that had to clip an operand, or a split launch that lost a partner workgroup, is reported by the NEXT call
- * (BUSCA_EINVAL / BUSCA_EHIP with the reason) and by busca_get_option("dt_status").
+ * BUSCA_PREC_F16X3 flavour that had to clip an operand, or a split launch that lost a partner workgroup, leaves a status word the caller reads once the
+ * stream is synchronised (busca_get_option "dt_status"; busca_amd's wrappers do, and re-run a clipped step with "dt_exact_f32") - a status nobody
+ * cleared is returned by the NEXT call (BUSCA_EINVAL / BUSCA_EHIP with the reason), whose own kernels are launched all the same.
  */
 int busca_dt_forward(busca_ctx* ctx, const float* mem_feat, const float* can_feat, const float* mem_ltrb,
                      const float* can_ltrb, int32_t B, int32_t L, int32_t P, float* logits, float* probs,
@@ -193,8 +202,8 @@ int busca_duplicate_masks(busca_ctx* ctx, const double* cost, int32_t nA, int32_
 /*
  * frame: dev u8 [H,W,3] (BGR, row stride `stride` bytes); boxes: dev f32 [n,4] x1y1x2y2.
  * out_u8 (may be NULL): dev u8 [n,384,128,3] BGR - exactly get_image_crops(normalize=False).
- * out_f16 (may be NULL): dev fp16 [n,384,128,4] RGB0 normalised ((x/255-mean)/std, ghost std), the
- *   ReID input layout of busca_reid_forward_f16in.
+ * out_f16 (may be NULL): dev fp16 [n,384,128,4] RGB0 normalised ((x/255-mean)/std, ghost std): the layout the fp16 ReID stem
+ *   stages internally (no entry point takes it; the ReID forwards read the u8 crops).
  */
 int busca_crop_gather(busca_ctx* ctx, const uint8_t* frame, int32_t H, int32_t W, int32_t stride,
                       const float* boxes, int32_t n, uint8_t* out_u8, void* out_f16, void* stream);

@@ -574,3 +574,36 @@ def test_associate_never_returns_a_clipped_x3_step(golden_dir):
     got1, _ = m3.associate_embeddings(tracks, dets, dists, 11, P, True, True, extra_kalman_candidates=kals, normalize_ims=True)
     want1, _ = m32.associate_embeddings(tracks, dets, dists, 11, P, True, True, extra_kalman_candidates=kals, normalize_ims=True)
     assert np.array_equal(got1, want1)
+
+
+def test_associate_reruns_an_overflowed_x3_reid_pass_in_f32(golden_dir):
+    """A ReID checkpoint whose activations leave the split-fp16 operand range (a BatchNorm affine x 4000): the default x3 extractor reports it (`reid_status` 2), and
+    associate_embeddings - synchronised on the probabilities - computes both BatchNorm batches of the step again on the exact-f32 extractor: the result is
+    what a model built with reid_precision="f32" returns, bit for bit, in this frame and the next, nothing raised; a healthy checkpoint is never re-run."""
+    from busca_amd.network import BUSCA
+
+    def build(reid_prec, hot):
+        a = _args(precision="x3")
+        a.reid_precision = reid_prec
+        m = BUSCA(a).to(torch.device("cuda:0")).eval()
+        sd = dict(synth.dt_state_dict(17, d=64, ff=128))
+        rsd = dict(synth.reid_state_dict(17))
+        if hot:
+            rsd["layer2.0.bn1.weight"] = rsd["layer2.0.bn1.weight"] * 4000.0
+            rsd["layer2.0.bn1.bias"] = rsd["layer2.0.bn1.bias"] * 4000.0
+        sd.update({"reid_encoder.model." + k: v for k, v in rsd.items()})
+        m.load_state_dict(sd)
+        return m
+
+    g = np.load(os.path.join(golden_dir, "assoc.npz"))
+    name, tracks, dets, kals, P = _case(2)
+    dists = g[name + "_dists"]
+    m32, m3, healthy = build("f32", True), build("x3", True), build("x3", False)
+    want, rel32 = m32.associate_embeddings(tracks, dets, dists, 11, P, True, False, extra_kalman_candidates=kals, normalize_ims=True)
+    assert np.isfinite(want).all()
+    for frame in range(2):
+        got, rel = m3.associate_embeddings(tracks, dets, dists, 11, P, True, False, extra_kalman_candidates=kals, normalize_ims=True)
+        assert np.array_equal(got, want) and np.array_equal(rel, rel32)
+        assert m3.reid_exact_reruns == frame + 1 and m3._ctx.get_option("reid_status") == 0
+    healthy.associate_embeddings(tracks, dets, dists, 11, P, True, False, extra_kalman_candidates=kals, normalize_ims=True)
+    assert getattr(healthy, "reid_exact_reruns", 0) == 0 and healthy._dt.exact_reruns == 0

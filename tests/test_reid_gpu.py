@@ -595,3 +595,35 @@ def test_reid_x3_persistent_tails_are_bit_identical(ctx, n):
     assert np.array_equal(one_shot, pers)
     assert np.array_equal(one_shot_w, pers_w)
     assert np.array_equal(m.forward(crops).cpu().numpy(), pers)          # the default schedule (persistent from 512 work items up) too
+
+
+@pytest.mark.parametrize("n,where", [(6, "layer1.0.bn1"), (44, "layer2.1.bn2"), (6, "layer3.2.bn3"), (130, "layer1.1.bn2")])
+def test_x3_reid_reports_operands_beyond_its_range(ctx, n, where):
+    """The split-fp16 flavour stages activations as fp16 hi + lo of 64 x and does not clamp: an activation beyond |x| = 1023.5 turns its conv's output and BatchNorm
+    statistics non-finite, and the pass raises `reid_status` 2 in host-mapped memory (the end-of-pass scan of the (scale, shift) table) instead of returning
+    features computed from clipped values (round-5 finding).  BatchNorm affines x 4000 in a first / middle / last conv of a bottleneck, small and large batch
+    schedules: the x3 pass reports, a healthy checkpoint never does, and the exact-f32 extractor takes the same checkpoint (<= 1e-4 from the oracle)."""
+    from busca_amd.reid import ReIDEncoderHIP
+    from oracle import reid as oreid
+    sd = synth.reid_state_dict(3)
+    crops = _crops(900 + n, n)
+    ok = ReIDEncoderHIP(ctx, sd, precision="x3")
+    f_ok = ok.forward(crops)
+    torch.cuda.synchronize()
+    assert ok.take_status() is False and np.isfinite(f_ok.cpu().numpy()).all()
+    hot = dict(sd)
+    hot[where + ".weight"] = sd[where + ".weight"] * 4000.0           # relu(bn(.)) of ~ 4000 x a few sigma
+    hot[where + ".bias"] = sd[where + ".bias"] * 4000.0
+    m3 = ReIDEncoderHIP(ctx, hot, precision="x3")
+    m3.forward(crops)
+    torch.cuda.synchronize()
+    assert ctx.get_option("reid_status") == 2
+    assert m3.take_status() is True and ctx.get_option("reid_status") == 0 and m3.take_status() is False
+    f32 = ReIDEncoderHIP(ctx, hot, precision="f32").forward(crops).cpu().numpy()
+    assert np.isfinite(f32).all()
+    if n <= 8:
+        want = oreid.reid_forward(hot, oreid.crops_to_reid_input(crops)).numpy()
+        assert np.abs(f32 - want).max() <= 1e-4
+    again = ReIDEncoderHIP(ctx, sd, precision="x3").forward(crops)      # a healthy model on the same context afterwards: clean status, same bits as before
+    torch.cuda.synchronize()
+    assert ctx.get_option("reid_status") == 0 and np.array_equal(again.cpu().numpy(), f_ok.cpu().numpy())
