@@ -701,7 +701,7 @@ def main():
         # cfg5 = BASELINE configs[4], one GPU's share is the full 512-track step here)
         cfgs = result.setdefault("configs", {})
         for name, cB, cP, cd, prec, cF, csteps in (("cfgR", 32, 5, 512, "x3", 8, 600), ("cfgR_f32", 32, 5, 512, "f32", 8, 400), ("cfgR_f16", 32, 5, 512, "f16", 8, 800),
-                                                   ("cfg4", 128, 32, 512, "f32", 2, 20), ("cfg4_f16", 128, 32, 512, "f16", 2, 60),
+                                                   ("cfg4", 128, 32, 512, "x3", 2, 40), ("cfg4_f32", 128, 32, 512, "f32", 2, 20), ("cfg4_f16", 128, 32, 512, "f16", 2, 60),
                                                    ("cfg5", 512, 64, 512, "f16", 1, 20)):
             try:
                 cfgs[name] = config_leg(ctx, dev, name, cB, L, cP, cd, prec, cF, csteps)
@@ -710,7 +710,7 @@ def main():
         try:        # BASELINE configs[3] as a FULL step (crops cut on the GPU, 1 408 + 4 096-crop BatchNorm batches, DT at T = 79)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import cfg4_step
-            cfgs["cfg4_full_step"] = cfg4_step.run(3, "x3", reid_precision="x3")               # library defaults (x3 ReID + x3 DT; T = 79 runs the exact f32 layer-wise path)
+            cfgs["cfg4_full_step"] = cfg4_step.run(3, "x3", reid_precision="x3")               # library defaults (x3 ReID + x3 DT: at T = 79 the split-fp16 layer-wise kernels)
             cfgs["cfg4_full_step_f16"] = cfg4_step.run(3, "f16", reid_precision="f16")          # opt-in fast flavours
             cfgs["cfg4_full_step_f16_expanded_batch"] = cfg4_step.run(3, "f16", dedup=False, reid_precision="f16")
         except Exception as e:

@@ -15,7 +15,7 @@ OUT = os.path.join(HERE, "libbusca_hip.so")
 STAMP = OUT + ".flags"
 # (unit, compiled with -amdgpu-mfma-vgpr-form where that compiles).  busca_dt_aux: the instantiations that crash that pass (see the file).
 UNITS = [("busca_hip", True), ("busca_dt_f32", True), ("busca_dt_f16", True), ("busca_dt_x3", True), ("busca_dt_aux", False),
-         ("busca_dtl_f32", True), ("busca_dtl_f16", True), ("busca_reid", True)]
+         ("busca_dtl_f32", True), ("busca_dtl_f16", True), ("busca_dtl_x3", True), ("busca_reid", True)]
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 

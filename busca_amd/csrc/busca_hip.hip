@@ -422,6 +422,12 @@ static int dt_forward_impl(busca_ctx* c, const float* mem_feat, const float* can
     // shapes beyond the fused kernel's on-chip plan: layer-wise tiled path, same arithmetic type (x3: the exact f32 layer-wise path on the f32 packing, proto32)
     if (prec == BUSCA_PREC_F16) return dt_tiled_f16(c, K, d, s);
     if (prec == BUSCA_PREC_F16X3) {
+        // the split-fp16 layer kernels where they are built (d >= 256, four heads, ff a multiple of d; T <= 80 for the fused QKV + attention kernel - beyond it
+        // that half of a layer runs the exact f32 kernels); else the exact f32 layer-wise path on the f32 packing (proto32)
+        if (d >= 256 && c->dt.cfg.nhead == 4) {
+            const int rc = dt_tiled_x3(c, K, d, s);
+            if (rc != BUSCA_ENOKERNEL) return rc;
+        }
         K.w_embed = c->dt.proto32.w_embed;
         for (int l = 0; l < K.nlayers; ++l) { K.layer[l].w_in = c->dt.proto32.layer[l].w_in; K.layer[l].w_out = c->dt.proto32.layer[l].w_out; K.layer[l].w1 = c->dt.proto32.layer[l].w1; K.layer[l].w2 = c->dt.proto32.layer[l].w2; }
     }

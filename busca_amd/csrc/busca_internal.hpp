@@ -2,7 +2,7 @@
 // offers the others).  The library is built from several units compiled in parallel (busca_amd/build.py):
 //   busca_hip.hip      context, options, timing, Decision-Transformer weight packing + dispatch, geometry / crop / tracking kernels and their C-ABI
 //   busca_dt_f32 / _f16 / _x3.hip   the fused Decision-Transformer kernel, one unit per arithmetic flavour   (+ busca_dt_aux.hip, see there)
-//   busca_dtl_f32 / _f16.hip        the layer-wise Decision-Transformer path
+//   busca_dtl_f32 / _f16 / _x3.hip  the layer-wise Decision-Transformer path
 //   busca_reid.hip     the ReID extractor (every flavour) and its C-ABI
 #pragma once
 #include <hip/hip_runtime.h>
@@ -136,6 +136,7 @@ int dt_fused_x3(busca_ctx* c, const DTParams& K, int MT, int d, hipStream_t s);
 // layer-wise path (busca_dtl_*.hip)
 int dt_tiled_f32(busca_ctx* c, const DTParams& K, int d, hipStream_t s);
 int dt_tiled_f16(busca_ctx* c, const DTParams& K, int d, hipStream_t s);
+int dt_tiled_x3(busca_ctx* c, const DTParams& K, int d, hipStream_t s);      // BUSCA_ENOKERNEL: no split-fp16 layer kernels for this width (the caller runs the exact f32 path)
 size_t dtl_ws_bytes(size_t M, int D, int FF, size_t es);
 int dtl_ws_ensure(busca_ctx* c, size_t need, hipStream_t s);
 void dt_bucket_ids_launch(busca_ctx* c, hipStream_t s, const float* mem_ltrb, const float* can_ltrb, int B, int L, int P, int fake_f64, int can_pos, int nspec, int sep_can, int* ids);

@@ -74,8 +74,9 @@ static int dtl_attention_hd(busca_ctx* c, hipStream_t s, int MT, const void* qkv
 // 128-wide, d = 256 / 64-wide) and the token counts the one-kernel path cannot hold.  Returns false when this shape is not built.
 template <int PREC, int D, int HD, int MT>
 static int dtl_qkv_attn_launch(busca_ctx* c, hipStream_t s, const DTLQkvAttnArgs& a, int B) {
-    constexpr int ES = Prec<PREC>::ES, CH = Prec<PREC>::CHUNK, TP = 16 * MT, TPK = CH * Prec<PREC>::nchunks(MT);
-    constexpr size_t ga = (size_t)TP * ((D / 2) * ES + 16), at = (size_t)2 * TP * (HD * ES + 16) + (size_t)HD * (TPK * ES + 16);
+    typedef typename AttPrec<PREC>::type AP;         // (x3: the attention tiles are the f32 kernel's)
+    constexpr int ES = Prec<PREC>::ES, AES = AP::ES, TP = 16 * MT, TPK = AP::CHUNK * AP::nchunks(MT);
+    constexpr size_t ga = (size_t)TP * ((D / 2) * ES + 16), at = (size_t)2 * TP * (HD * AES + 16) + (size_t)HD * (TPK * AES + 16);
     constexpr size_t lds = ga > at ? ga : at;
     static_assert(lds <= 160 * 1024, "fused QKV + attention: LDS plan");
     auto kern = dtl_qkv_attn_kernel<PREC, D, HD, MT>;
@@ -100,6 +101,10 @@ template <int PREC, int D>
 static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     DTState& S = c->dt;
     constexpr size_t ES = Prec<PREC>::ES;
+    // GP: arithmetic of the generic GEMM / attention kernels (embed, geometries the fused layer kernels are not built for).  x3 has the two fused layer
+    // kernels only (dtl_qkv_attn_kernel<2>, dtl_ffn_kernel<2>: split-fp16 products, float32-equivalent); everything else of an x3 forward runs the exact
+    // f32 kernels on the row-major f32 matrices (S.tw) - never less than float32-equivalent.
+    constexpr int GP = PREC == 2 ? 0 : PREC;
     const int T = K.T, B = K.B, L = K.L, P = K.P, FF = S.cfg.ff, NH = S.cfg.nhead, E = 512;
     const int MT = (T + 15) / 16;
     if (MT > 9) return fail(c, BUSCA_EINVAL, "tiled DT path supports at most 144 tokens per track (T=%d)", T);
@@ -114,7 +119,7 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     char* O = p; p += al(M * D * ES);
     char* H = p; p += al(M * FF * ES);
     int* ids = (int*)p;
-    const void* Xop = PREC == 0 ? (const void*)X : (const void*)Xh;      // GEMM operand copy of the residual stream
+    const void* Xop = PREC != 1 ? (const void*)X : (const void*)Xh;      // GEMM operand copy of the residual stream
     dt_bucket_ids_launch(c, s, K.mem_ltrb, K.can_ltrb, B, L, P, K.fake_f64, K.can_pos, K.nspec, K.sep_can, ids);
     DTLArgs a{};
     a.M = (int)M; a.L = L; a.P = P; a.T = T; a.E = E; a.can_pos = K.can_pos; a.X = X; a.Xh = Xh; a.act = K.act;
@@ -124,14 +129,14 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     a.lut_xy = K.lut_xy; a.lut_sz = K.lut_sz; a.lut_t = K.lut_t; a.lut_c = K.lut_c;
     a.tok_sep = K.tok_sep; a.tok_non = K.tok_non; a.tok_bad = K.tok_bad;
     a.skip_x32 = (PREC == 1 && D >= 256 && c->opt.dtl_ffn == 2) ? 1 : 0;       // every layer then runs dtl_ffn_kernel<.., OUTPROJ>, which carries the stream in Xh
-    { int rc = dtl_gemm<PREC, D, DTL_EPI_EMBED>(c, s, a, 1); if (rc) return rc; }
+    { int rc = dtl_gemm<GP, D, DTL_EPI_EMBED>(c, s, a, 1); if (rc) return rc; }
     for (int l = 0; l < K.nlayers; ++l) {
         const DTLayerW& W = K.layer[l];
         float* att = K.att ? K.att + (size_t)l * B * NH * T * T : nullptr;
         bool fused_attn = false;
         if (c->opt.dtl_attn != 0) {
             DTLQkvAttnArgs q{};
-            q.Xop = Xop; q.w_in = W.w_in; q.b_in = W.b_in; q.O = O; q.att = att; q.T = T; q.NH = NH; q.qscale = a.qscale;
+            q.Xop = Xop; q.w_in = W.w_in; q.b_in = W.b_in; q.O = O; q.att = att; q.T = T; q.NH = NH; q.qscale = a.qscale; q.xerr = K.xerr;
             int rc = BUSCA_OK;
             fused_attn = dtl_qkv_attn<PREC, D>(c, s, q, B, MT, &rc);
             if (rc) return rc;
@@ -139,21 +144,22 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
         if (!fused_attn) {
             a.A = Xop; a.lda = D; a.W = S.tw.w_in[l]; a.K = D; a.bias = W.b_in; a.out16 = QKV; a.ldo = 3 * D;
             {
-                int rc = dtl_gemm<PREC, D, DTL_EPI_QKV>(c, s, a, 3);
+                int rc = dtl_gemm<GP, D, DTL_EPI_QKV>(c, s, a, 3);
                 if (rc) return rc;
             }
-            { int rc = dtl_attention_hd<PREC>(c, s, MT, QKV, O, B, T, D, NH, att); if (rc) return rc; }
+            { int rc = dtl_attention_hd<GP>(c, s, MT, QKV, O, B, T, D, NH, att); if (rc) return rc; }
         }
         const int ffn_mode = D >= 256 ? c->opt.dtl_ffn : 0;   // 2: out-proj + norm1 + feed-forward + norm2 in one kernel; 1: feed-forward block only; 0: layer-wise GEMMs
         if (ffn_mode != 2) {
             a.A = O; a.lda = D; a.W = S.tw.w_out[l]; a.K = D; a.bias = W.b_out; a.gamma = W.g1; a.beta = W.be1;
-            { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
+            { int rc = dtl_gemm<GP, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
         }
         if (ffn_mode != 0) {
             // the row-local half of the layer in one kernel: x1 (mode 2) and H never reach HBM (dtl_ffn_kernel)
             DTLFfnArgs f{};
             f.Xop = Xop; f.Oop = O; f.X = X; f.Xh = Xh; f.w_out = W.w_out; f.w1 = W.w1; f.w2 = W.w2; f.b_out = W.b_out; f.g1 = W.g1; f.be1 = W.be1;
             f.b1 = W.b1; f.b2 = W.b2; f.gamma = W.g2; f.beta = W.be2; f.M = (int)M; f.FF = FF; f.act = K.act;
+            f.xerr = K.xerr;
             f.write_x32 = l == K.nlayers - 1;            // (f16 flavour: the float32 copy of the residual stream only where the decoder / `hidden` read it)
             constexpr int DK = D >= 256 ? D : 256;
             constexpr int BMF = DTLFfnGeom<PREC, DK>::BM;
@@ -172,11 +178,11 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
         }
         a.A = Xop; a.lda = D; a.W = S.tw.w1[l]; a.K = D; a.bias = W.b1; a.out16 = H; a.ldo = FF;
         {
-            int rc = dtl_gemm<PREC, D, DTL_EPI_FFN1>(c, s, a, FF / D);
+            int rc = dtl_gemm<GP, D, DTL_EPI_FFN1>(c, s, a, FF / D);
             if (rc) return rc;
         }
         a.A = H; a.lda = FF; a.W = S.tw.w2[l]; a.K = FF; a.bias = W.b2; a.gamma = W.g2; a.beta = W.be2;
-        { int rc = dtl_gemm<PREC, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
+        { int rc = dtl_gemm<GP, D, DTL_EPI_RESLN>(c, s, a, 1); if (rc) return rc; }
     }
     if (K.hidden) HIP_TRY(c, hipMemcpyAsync(K.hidden, X, M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     { TimedLaunch tl(c, s);

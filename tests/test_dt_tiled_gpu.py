@@ -32,10 +32,11 @@ def force_tiled(ctx):
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
 @pytest.mark.parametrize("mode", ["f64", "f32"])
-@pytest.mark.parametrize("prec", ["f16", "f32"])
+@pytest.mark.parametrize("prec", ["f16", "f32", "x3"])
 def test_tiled_vs_reference_golden(ctx, force_tiled, path, mode, prec):
+    """(x3: the split-fp16 layer kernels at d >= 256 - float32-equivalent, held to the f32 bars; d = 64 runs the exact f32 kernels.)"""
     from busca_amd.dt import DecisionTransformerHIP
-    TOL = TOL32 if prec == "f32" else globals()["TOL"]
+    TOL = TOL32 if prec in ("f32", "x3") else globals()["TOL"]
     g = np.load(path)
     d, ff, B, L, P, seed = (int(g[k]) for k in ("d", "ff", "B", "L", "P", "seed"))
     sd = synth.dt_state_dict(seed, d=d, ff=ff)
@@ -60,14 +61,14 @@ def test_tiled_vs_reference_golden(ctx, force_tiled, path, mode, prec):
 
 @pytest.mark.parametrize("shape", [(128, 11, 32, 512), (24, 11, 64, 512), (40, 11, 40, 256), (9, 11, 62, 64)],
                          ids=["cfg4_128x32_d512", "cfg5_shape_x64_d512", "T95_d256", "T139_d64"])
-@pytest.mark.parametrize("prec", ["f16", "f32"])
+@pytest.mark.parametrize("prec", ["f16", "f32", "x3"])
 def test_tiled_large_shapes_vs_oracle(ctx, shape, prec):
     """Shapes the fused kernel cannot hold (dispatch picks the tiled path by itself), in both arithmetic types: the f32
     flavour (v_mfma_f32_16x16x4_f32, the reference's own precision, busca/custom_layers.py:30-41) to the float32
     tolerances of test_dt_gpu.py - BASELINE configs[3] (128 x 32, T = 79) at reference precision."""
     from busca_amd.dt import DecisionTransformerHIP
     from oracle import dt as odt
-    TOL = TOL32 if prec == "f32" else globals()["TOL"]
+    TOL = TOL32 if prec in ("f32", "x3") else globals()["TOL"]
     B, L, P, d = shape
     seed = 300 + P + d
     sd = synth.dt_state_dict(seed, d=d, ff=2 * d)
@@ -86,10 +87,12 @@ def test_tiled_large_shapes_vs_oracle(ctx, shape, prec):
     assert (out["argmax"][clear] == ref["argmax"].numpy()[clear]).all()
 
 
-@pytest.mark.parametrize("shape", [(16, 11, 32, 512), (6, 11, 40, 256)], ids=lambda s: "B%d_L%d_P%d_d%d" % s)
-def test_x3_beyond_the_one_kernel_shapes_is_the_exact_f32_path(ctx, shape):
-    """The split-fp16 flavour (the default) is built for the one-kernel path; a shape beyond it runs the exact f32 layer-wise kernels on an f32 packing of
-    the same weights: outputs bit-identical to the f32 flavour's (round 5: the x3-packed weights must never reach an f32 kernel)."""
+@pytest.mark.parametrize("shape", [(16, 11, 32, 512), (6, 11, 30, 256), (5, 11, 64, 512), (4, 11, 40, 64)], ids=lambda s: "B%d_L%d_P%d_d%d" % s)
+def test_x3_beyond_the_one_kernel_shapes(ctx, shape):
+    """The split-fp16 flavour (the default) beyond the one-kernel path (round 6): the two fused layer kernels run their GEMMs as three fp16 MFMAs per product
+    block on hi / lo operands (d >= 256; T <= 80 for the QKV + attention kernel - at T = 143 that half of a layer runs the exact f32 kernels), d = 64 runs the
+    exact f32 layer-wise path (bit-identical to the f32 flavour).  Float32-equivalent: logits within 5e-5 of the exact f32 flavour's, same argmax outside a
+    1e-4 margin, `dt_status` 0; and `dt_exact_f32` gives the f32 flavour's bits on the same context (the re-run route of a clipped step)."""
     from busca_amd.dt import DecisionTransformerHIP
     B, L, P, d = shape
     sd = synth.dt_state_dict(70 + d, d=d, ff=2 * d)
@@ -100,8 +103,27 @@ def test_x3_beyond_the_one_kernel_shapes_is_the_exact_f32_path(ctx, shape):
         o = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"], want_hidden=True)
         torch.cuda.synchronize()
         outs[prec] = {k: v.cpu().numpy() for k, v in o.items()}
-    for k in ("logits", "probs", "argmax", "hidden"):
-        assert np.array_equal(outs["f32"][k], outs["x3"][k]), k
+        assert ctx.get_option("dt_status") == 0
+        if prec == "x3":
+            ctx.set_option("dt_exact_f32", 1)
+            try:
+                e = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"], want_hidden=True)
+                torch.cuda.synchronize()
+            finally:
+                ctx.set_option("dt_exact_f32", 0)
+            for k in ("logits", "probs", "argmax", "hidden"):
+                assert np.array_equal(e[k].cpu().numpy(), outs["f32"][k]), k
+    if d == 64:
+        for k in ("logits", "probs", "argmax", "hidden"):
+            assert np.array_equal(outs["f32"][k], outs["x3"][k]), k
+    else:
+        assert not np.array_equal(outs["f32"]["logits"], outs["x3"]["logits"])            # it IS another kernel
+        assert np.abs(outs["f32"]["logits"] - outs["x3"]["logits"]).max() <= 5e-5
+        assert np.abs(outs["f32"]["probs"] - outs["x3"]["probs"]).max() <= 5e-6
+        assert np.abs(outs["f32"]["hidden"] - outs["x3"]["hidden"]).max() <= 1e-4
+        srt = np.sort(outs["f32"]["probs"], axis=-1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-4
+        assert (outs["f32"]["argmax"][clear] == outs["x3"]["argmax"][clear]).all()
     assert np.abs(outs["x3"]["logits"]).max() > 0 and np.ptp(outs["x3"]["logits"]) > 1e-3
 
 
