@@ -327,25 +327,18 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
         S.tw.w_embed = tb + o_e;
         for (int l = 0; l < g->nlayers; ++l) { S.tw.w_in[l] = tb + oi[l]; S.tw.w_out[l] = tb + oo[l]; S.tw.w1[l] = tb + o1[l]; S.tw.w2[l] = tb + o2[l]; }
     }
-    {   // exchange buffers of the token-split tail: one round's worth of tracks (two workgroups each), sized for this width
+    {   // token-split tail: its exchange buffers (64 / 128 MiB at d = 256 / 512) are allocated by the first launch that splits (dt_split_ensure) - a context that
+        // never splits (the f16 flavour by default, bench.py's extra contexts) never pays for them; only the status word lives from here on
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) S.num_cu = prop.multiProcessorCount; }
-        if (S.xch) { HIP_TRY(c, hipFree(S.xch)); S.xch = nullptr; }
+        if (S.xch) { HIP_TRY(c, hipDeviceSynchronize()); HIP_TRY(c, hipFree(S.xch)); S.xch = nullptr; }
         if (S.xflag) { HIP_TRY(c, hipFree(S.xflag)); S.xflag = nullptr; }
         if (S.xlg) { HIP_TRY(c, hipFree(S.xlg)); S.xlg = nullptr; }
-        S.xslots = S.num_cu;
-        const size_t per_slot = (size_t)2 * DT_XMAX_MT * 4 * (2 * (d / 64)) * 1024;       // parity x tile x wave x (K, V tiles of a head) x 64 lanes x 16 bytes
-        if (d % 64 == 0) {
-            HIP_TRY(c, hipMalloc(&S.xch, per_slot * S.xslots));
-            HIP_TRY(c, hipMalloc((void**)&S.xflag, (size_t)S.xslots * DT_XMAX_MT * DT_XFLAGS * sizeof(unsigned)));
-            HIP_TRY(c, hipMemset(S.xflag, 0, (size_t)S.xslots * DT_XMAX_MT * DT_XFLAGS * sizeof(unsigned)));
-            HIP_TRY(c, hipMalloc((void**)&S.xlg, (size_t)S.xslots * DT_XMAX_MT * 16 * sizeof(float)));
-            if (!S.xerr) {
-                HIP_TRY(c, hipHostMalloc((void**)&S.xerr, sizeof(int), hipHostMallocMapped)); *S.xerr = 0;
-                HIP_TRY(c, hipHostGetDevicePointer((void**)&S.xerr_dev, S.xerr, 0));
-            }
-            S.xepoch = 0;
-            HIP_TRY(c, hipDeviceSynchronize());
-        } else S.xslots = 0;
+        S.xslots = d % 64 == 0 ? S.num_cu : 0;
+        if (!S.xerr) {
+            HIP_TRY(c, hipHostMalloc((void**)&S.xerr, sizeof(int), hipHostMallocMapped)); *S.xerr = 0;
+            HIP_TRY(c, hipHostGetDevicePointer((void**)&S.xerr_dev, S.xerr, 0));
+        }
+        S.xepoch = 0;
     }
     S.loaded = true;
     return BUSCA_OK;
@@ -364,6 +357,23 @@ int dtl_ws_ensure(busca_ctx* c, size_t need, hipStream_t s) {
     if (S.ws) { HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(S.ws)); S.ws = nullptr; S.ws_bytes = 0; }
     if (hipMalloc(&S.ws, need) != hipSuccess) return fail(c, BUSCA_ENOMEM, "cannot allocate %zu bytes of DT workspace", need);
     S.ws_bytes = need;
+    return BUSCA_OK;
+}
+
+// Exchange buffers of the token-split tail: one round's worth of tracks (two workgroups each), sized for the loaded width; allocated by the first launch that
+// splits (one device synchronisation + three hipMallocs, once per weight set).
+int dt_split_ensure(busca_ctx* c) {
+    DTState& S = c->dt;
+    if (S.xch != nullptr) return BUSCA_OK;
+    if (S.xslots <= 0) return fail(c, BUSCA_EINVAL, "token-split launch without exchange slots");
+    const int d = S.cfg.d;
+    const size_t per_slot = (size_t)2 * DT_XMAX_MT * 4 * (2 * (d / 64)) * 1024;       // parity x tile x wave x (K, V tiles of a head) x 64 lanes x 16 bytes
+    HIP_TRY(c, hipMalloc(&S.xch, per_slot * S.xslots));
+    HIP_TRY(c, hipMalloc((void**)&S.xflag, (size_t)S.xslots * DT_XMAX_MT * DT_XFLAGS * sizeof(unsigned)));
+    HIP_TRY(c, hipMemset(S.xflag, 0, (size_t)S.xslots * DT_XMAX_MT * DT_XFLAGS * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc((void**)&S.xlg, (size_t)S.xslots * DT_XMAX_MT * 16 * sizeof(float)));
+    S.xepoch = 0;
+    HIP_TRY(c, hipDeviceSynchronize());
     return BUSCA_OK;
 }
 

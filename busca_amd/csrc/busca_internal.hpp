@@ -137,6 +137,7 @@ int dt_fused_x3(busca_ctx* c, const DTParams& K, int MT, int d, hipStream_t s);
 int dt_tiled_f32(busca_ctx* c, const DTParams& K, int d, hipStream_t s);
 int dt_tiled_f16(busca_ctx* c, const DTParams& K, int d, hipStream_t s);
 int dt_tiled_x3(busca_ctx* c, const DTParams& K, int d, hipStream_t s);      // BUSCA_ENOKERNEL: no split-fp16 layer kernels for this width (the caller runs the exact f32 path)
+int dt_split_ensure(busca_ctx* c);                 // allocates the token-split exchange buffers on first use (busca_hip.hip)
 size_t dtl_ws_bytes(size_t M, int D, int FF, size_t es);
 int dtl_ws_ensure(busca_ctx* c, size_t need, hipStream_t s);
 void dt_bucket_ids_launch(busca_ctx* c, hipStream_t s, const float* mem_ltrb, const float* can_ltrb, int B, int L, int P, int fake_f64, int can_pos, int nspec, int sep_can, int* ids);

@@ -54,6 +54,7 @@ static int dt_launch_split(busca_ctx* c, const DTParams& P0, int nsplit, hipStre
     DTState& S = c->dt;
     auto kern = dt_fused_kernel<PREC, MT, D, FF, 512, NCH, NTRK, true>;
     const int nwg = ((nsplit + NTRK - 1) / NTRK) * MT;
+    { int rc = dt_split_ensure(c); if (rc) return rc; }
     DTParams P = P0;
     P.nsingle = P.B - nsplit;
     P.xepoch = ++S.xepoch; P.xch = (unsigned long long*)S.xch; P.xflag = S.xflag; P.xlg = S.xlg; P.xerr = S.xerr_dev;

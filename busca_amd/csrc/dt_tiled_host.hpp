@@ -11,7 +11,9 @@ static int dtl_gemm_rt(busca_ctx* c, hipStream_t s, const DTLArgs& a, int ncolbl
     auto kern = dtl_gemm_kernel<PREC, D, EPI, RT>;
     { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
     TimedLaunch tl(c, s);
-    hipLaunchKernelGGL(kern, dim3((a.M + BM - 1) / BM, ncolblocks), dim3(512), lds, s, a);
+    // (embed pass: GEMM workgroups for the compacted feature rows, then the workgroups that fill the special token rows)
+    const int nbx = EPI == DTL_EPI_EMBED ? (a.Me + BM - 1) / BM + (a.M - a.Me + BM - 1) / BM : (a.M + BM - 1) / BM;
+    hipLaunchKernelGGL(kern, dim3(nbx, ncolblocks), dim3(512), lds, s, a);
     return BUSCA_OK;
 }
 
@@ -128,6 +130,7 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     a.W = S.tw.w_embed; a.K = E; a.bias = K.b_embed; a.mem_feat = K.mem_feat; a.can_feat = K.can_feat; a.ids = ids;
     a.lut_xy = K.lut_xy; a.lut_sz = K.lut_sz; a.lut_t = K.lut_t; a.lut_c = K.lut_c;
     a.tok_sep = K.tok_sep; a.tok_non = K.tok_non; a.tok_bad = K.tok_bad;
+    a.Me = B * (L + P);
     a.skip_x32 = (PREC == 1 && D >= 256 && c->opt.dtl_ffn == 2) ? 1 : 0;       // every layer then runs dtl_ffn_kernel<.., OUTPROJ>, which carries the stream in Xh
     { int rc = dtl_gemm<GP, D, DTL_EPI_EMBED>(c, s, a, 1); if (rc) return rc; }
     for (int l = 0; l < K.nlayers; ++l) {

@@ -26,6 +26,7 @@ dt_f32_F8_B32_P5_d512 256 5 512 f32
 dt_f16_F8_B32_P5_d512 256 5 512 f16
 dt_f32_F2_B128_P32_d512 256 32 512 f32
 dt_f16_F2_B128_P32_d512 256 32 512 f16
+dt_x3_F2_B128_P32_d512 256 32 512 x3
 dt_f16_F1_B512_P64_d512 512 64 512 f16
 LIST
 python3 tools/pmc_dt_traffic.py $OUT > $OUT/entries.json
