@@ -606,12 +606,19 @@ def main():
     run.run_steps(args.warmup)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # the roofline's kernel time is measured LIVE, over the timed region itself: HIP events around every kernel launch of the K steps, on the launch stream
+    # (busca_timing_*: two hipEventRecord per launch, read back after the closing barrier)
+    ctx.lib.busca_timing_read(ctx.h, None, None, 1)
+    ctx.lib.busca_timing_enable(ctx.h, 1)
     t0 = time.perf_counter()
     ev0.record()
     n_launch = run.run_steps(args.steps)
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    k_avg, k_n = C.c_double(0), C.c_int64(0)
+    ctx.lib.busca_timing_read(ctx.h, C.byref(k_avg), C.byref(k_n), 1)
+    ctx.lib.busca_timing_enable(ctx.h, 0)
     my_elapsed = elapsed
     ev_ms = ev0.elapsed_time(ev1)
     elapsed = sharding.max_over_ranks(elapsed, dist, red_dev)
@@ -623,11 +630,9 @@ def main():
         ranks = [None] * world
         dist.all_gather_object(ranks, me)
 
-    # ---- roofline leg: the same launches, each bracketed by HIP events on the launch stream -------------------
-    timing = run.kernel_time(min(args.steps, 50 * F))
+    # ---- roofline: the timed launches' own event brackets ---------------------------------------------------------
     geom = run.geometry()
-    if not timing[1]:
-        timing = (ev_ms, n_launch, n_launch, args.steps)
+    timing = (k_avg.value * k_n.value, k_n.value, n_launch, args.steps) if k_n.value else (ev_ms, n_launch, n_launch, args.steps)
     p50 = run.p50_latency_ms(args.latency_samples)
 
     # ---- BASELINE configs[4] with one step's tracks split over the ranks: every rank takes part ------------------

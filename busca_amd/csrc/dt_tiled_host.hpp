@@ -83,8 +83,23 @@ static int dtl_qkv_attn_launch(busca_ctx* c, hipStream_t s, const DTLQkvAttnArgs
     static_assert(lds <= 160 * 1024, "fused QKV + attention: LDS plan");
     auto kern = dtl_qkv_attn_kernel<PREC, D, HD, MT>;
     { int rc = ensure_lds(c, (const void*)kern, lds); if (rc) return rc; }
+#ifdef BUSCA_CONV_PROBE
+    if (getenv("BUSCA_QA_TS")) {        // phase stamps (probe build): wave 0 of every workgroup, 100 MHz s_memtime ticks summed over the launch
+        static unsigned long long* ts = nullptr;
+        if (!ts) hipMalloc((void**)&ts, 8 * 8);
+        hipMemsetAsync(ts, 0, 64, s);
+        DTLQkvAttnArgs b = a; b.ts = ts;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.NH * 8 * ((B + 7) / 8))), dim3(4 * HD), lds, s, b);
+        hipStreamSynchronize(s);
+        unsigned long long h[8]; hipMemcpy(h, ts, 64, hipMemcpyDeviceToHost);
+        const double n = (double)B * a.NH; double tot = 0; for (int k = 0; k < 7; ++k) tot += (double)h[k];
+        fprintf(stderr, "[qa_ts] %d workgroups, mean lifetime of wave 0: %.0f ticks | stage half 0 %.0f, GEMM half 0 %.0f, stage half 1 %.0f, GEMM half 1 %.0f, barrier %.0f, park Q K V^T %.0f, attention + O %.0f\n",
+                B * a.NH, tot / n, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[6] / n);
+        return BUSCA_OK;
+    }
+#endif
     TimedLaunch tl(c, s);
-    hipLaunchKernelGGL(kern, dim3(B, a.NH), dim3(4 * HD), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.NH * 8 * ((B + 7) / 8))), dim3(4 * HD), lds, s, a);      // 1-D: the kernel maps a workgroup to (track, head) XCD-aware
     return BUSCA_OK;
 }
 template <int PREC, int D>
@@ -139,7 +154,7 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
         bool fused_attn = false;
         if (c->opt.dtl_attn != 0) {
             DTLQkvAttnArgs q{};
-            q.Xop = Xop; q.w_in = W.w_in; q.b_in = W.b_in; q.O = O; q.att = att; q.T = T; q.NH = NH; q.qscale = a.qscale; q.xerr = K.xerr;
+            q.Xop = Xop; q.w_in = W.w_in; q.b_in = W.b_in; q.O = O; q.att = att; q.T = T; q.NH = NH; q.qscale = a.qscale; q.xerr = K.xerr; q.B = B;
             int rc = BUSCA_OK;
             fused_attn = dtl_qkv_attn<PREC, D>(c, s, q, B, MT, &rc);
             if (rc) return rc;
