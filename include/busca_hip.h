@@ -62,7 +62,7 @@ const char* busca_build_info(void);
  *                   pays (f32 / x3), 0 = never, 1 / 2 = every track that fits, one / two tracks per workgroup (tests)
  *   "dt_exact_f32"  1 = a context loaded with BUSCA_PREC_F16X3 runs its forwards in exact float32 on the f32 packing it keeps of the same weights (how the
  *                   host re-runs a step whose x3 forward reported a clipped operand)
- *   "dt_status"     get: 0 ok, 1 = a token-split launch lost a partner workgroup, 2 = an operand of a BUSCA_PREC_F16X3 forward left the split-fp16 range (|x| > 1023.5: nothing is clipped, the affected token rows are non-finite) -
+ *   "dt_status"     get: 0 ok, 1 = a token-split launch lost a partner workgroup, 2 = a BUSCA_PREC_F16X3 forward had to clip an operand beyond |x| = 1023.5 -
  *                   valid once the forward's stream is synchronised; set 0: the caller has dealt with it (an uncleared status is returned by the next forward)
  *   "reid_status"   get: 0 ok, 2 = a BUSCA_PREC_F16X3 ReID forward since the last clear staged an activation beyond |x| = 1023.5 (its features are invalid:
  *                   non-finite BatchNorm statistics; nothing is clipped silently) - valid once the forwards' streams are synchronised; set 0 clears
@@ -126,8 +126,7 @@ int busca_dt_load_weights(busca_ctx* ctx, const busca_dt_cfg* cfg, const float* 
  *   att      [nlayers,B,nhead,T,T] f32 per-head attention weights              (may be NULL)
  * One Decision-Transformer forward per context at a time (its layer-wise workspace and the exchange buffers of the token-split tail belong
  * to the context; forwards on ONE stream are ordered by the stream - use one context per concurrently running stream).  A forward of the
- * BUSCA_PREC_F16X3 flavour with an operand beyond its range (|x| > 1023.5: non-finite results, never silently clipped ones), or a split launch that lost a partner
- * workgroup, leaves a status word the caller reads once the
+ * BUSCA_PREC_F16X3 flavour that had to clip an operand, or a split launch that lost a partner workgroup, leaves a status word the caller reads once the
  * stream is synchronised (busca_get_option "dt_status"; busca_amd's wrappers do, and re-run a clipped step with "dt_exact_f32") - a status nobody
  * cleared is returned by the NEXT call (BUSCA_EINVAL / BUSCA_EHIP with the reason), whose own kernels are launched all the same.
  */
