@@ -24,6 +24,8 @@ def _requested_flags():
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value"]
     if os.environ.get("BUSCA_CONV_PROBE"):      # s_memtime phase stamps in the ReID conv kernels (BUSCA_CONV_TS); costs ~1 %, off by default
         flags.append("-DBUSCA_CONV_PROBE")
+    if os.environ.get("BUSCA_SPLIT_RELAXED"):   # A/B only: the token-split hand-off without its agent-scope fences (dt_kernel.hip.inc)
+        flags.append("-DBUSCA_SPLIT_RELAXED")
     return flags
 
 

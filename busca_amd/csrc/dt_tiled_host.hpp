@@ -182,6 +182,28 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
             constexpr int DK = D >= 256 ? D : 256;
             constexpr int BMF = DTLFfnGeom<PREC, DK>::BM;
             constexpr size_t flds = DTLFfnGeom<PREC, DK>::LDS;
+#ifdef BUSCA_CONV_PROBE
+            if (ffn_mode == 2 && getenv("BUSCA_FFN_TS")) {      // phase stamps (probe build): per-wave cycle sums of the first 1 024 workgroups
+                static unsigned long long* ts = nullptr;
+                const int NWVp = DTLFfnGeom<PREC, DK>::NWV;
+                if (!ts) hipMalloc((void**)&ts, (size_t)1024 * 8 * 8 * 8);
+                hipMemsetAsync(ts, 0, (size_t)1024 * 8 * 8 * 8, s);
+                f.ts = ts; f.dbg_h = nullptr;
+                auto kern = dtl_ffn_kernel<PREC, DK, true>;
+                { int rc = ensure_lds(c, (const void*)kern, flds); if (rc) return rc; }
+                const unsigned nb = (unsigned)((M + BMF - 1) / BMF);
+                hipLaunchKernelGGL(kern, dim3(nb), dim3(64 * NWVp), flds, s, f);
+                hipStreamSynchronize(s);
+                std::vector<unsigned long long> hts((size_t)1024 * 8 * 8);
+                hipMemcpy(hts.data(), ts, hts.size() * 8, hipMemcpyDeviceToHost);
+                double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const int nbs = nb < 1024 ? (int)nb : 1024;
+                for (int b = 0; b < nbs; ++b) for (int w = 0; w < NWVp; ++w) for (int k = 0; k < 8; ++k) ph[k] += (double)hts[((size_t)b * NWVp + w) * 8 + k];
+                double tot = 0; for (int k = 0; k < 8; ++k) { ph[k] /= (double)nbs * NWVp; tot += ph[k]; }
+                fprintf(stderr, "[ffn_ts] %u workgroups x %d waves, mean wave lifetime %.0f cycles | stage rows %.0f, out-proj GEMM %.0f, residual + LN1 + x1 %.0f, FFN1 GEMMs %.0f, activation + barrier %.0f, FFN2 GEMMs %.0f, block barrier %.0f, residual + LN2 + stores %.0f\n",
+                        nb, NWVp, tot, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+                continue;
+            }
+#endif
             TimedLaunch tl(c, s);
             if (ffn_mode == 2) {
                 auto kern = dtl_ffn_kernel<PREC, DK, true>;
