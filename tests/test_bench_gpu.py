@@ -21,8 +21,8 @@ def _last_json(out, launcher_noise=False):
     """stdout must be exactly ONE line, short enough for the driver to keep whole, and it must parse.  (Under torch.distributed.run the gloo test backend's
     C++ prints its own "[Gloo] Rank ..." lines on the children's stdout: those runs must hold exactly one JSON line.)"""
     lines = out.strip().splitlines()
-    if launcher_noise:
-        lines = [l for l in lines if not l.startswith("[Gloo]")]
+    if launcher_noise:        # (the two ranks' "[Gloo] Rank ..." prints interleave arbitrarily, empty lines included: everything that is not a JSON object is the launcher's)
+        lines = [l for l in lines if l.startswith("{")]
     assert len(lines) == 1 and lines[0].startswith("{"), out[-2000:]
     assert len(lines[0]) <= MAX_LINE, len(lines[0])
     return json.loads(lines[0])
