@@ -243,6 +243,8 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
     }
     const size_t o_dg = put_vec(take(d), d), o_db = put_vec(take(d), d), o_dw = put_vec(take(d), d);
     const float dec_bias = *take(1);
+    double dec_cb = (double)dec_bias;                    // (the three decoder vectors sit right in front of the bias)
+    for (int f = 0; f < d; ++f) dec_cb += (double)(cur - 1 - 2 * d)[f] * (double)(cur - 1 - d)[f];
     auto put_lut = [&](const uint16_t* src, size_t rows) { size_t off = reserve(rows * lut_c * 2); memcpy(host.data() + off, src, rows * lut_c * 2); return off; };
     const size_t o_lxy = put_lut(lut_xy, 211), o_lsz = put_lut(lut_sz, 211), o_lt = put_lut(lut_t, 61);
 
@@ -267,7 +269,7 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
         W.g2 = (const float*)(base + lo[l].g2); W.be2 = (const float*)(base + lo[l].be2);
     }
     P.dec_g = (const float*)(base + o_dg); P.dec_b = (const float*)(base + o_db); P.dec_w = (const float*)(base + o_dw);
-    P.dec_bias = dec_bias;
+    P.dec_bias = dec_bias; P.dec_cb = (float)dec_cb;
     P.lut_xy = (const _Float16*)(base + o_lxy); P.lut_sz = (const _Float16*)(base + o_lsz); P.lut_t = (const _Float16*)(base + o_lt);
     P.lut_c = lut_c;
     P.nlayers = g->nlayers; P.act = g->activation; P.fake_f64 = g->fake_bbox_f64;
@@ -348,7 +350,7 @@ extern "C" int busca_dt_load_weights(busca_ctx* c, const busca_dt_cfg* g, const 
 // it too small grows it itself (one stream synchronisation + hipMalloc, first call of a larger shape only).
 size_t dtl_ws_bytes(size_t M, int D, int FF, size_t es) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return al(M * D * 4) + al(M * D * 2) + al(M * 3 * D * es) + al(M * D * es) + al(M * FF * es) + al(M * 3 * 4);
+    return al(M * D * 4) + al(M * D * 2) + al(M * 3 * D * es) + al(M * D * es) + al(M * FF * es) + al(M * 3 * 4) + al(M * 4);
 }
 
 int dtl_ws_ensure(busca_ctx* c, size_t need, hipStream_t s) {

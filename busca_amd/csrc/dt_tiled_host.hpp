@@ -135,7 +135,9 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     char* QKV = p; p += al(M * 3 * D * ES);
     char* O = p; p += al(M * D * ES);
     char* H = p; p += al(M * FF * ES);
-    int* ids = (int*)p;
+    int* ids = (int*)p; p += al(M * 3 * 4);
+    float* rowlogit = (float*)p;                          // [M] decoder logit of every row (last layer kernel) -> dtl_decoder_rows_kernel
+    bool dec_fused = false;
     const void* Xop = PREC != 1 ? (const void*)X : (const void*)Xh;      // GEMM operand copy of the residual stream
     dt_bucket_ids_launch(c, s, K.mem_ltrb, K.can_ltrb, B, L, P, K.fake_f64, K.can_pos, K.nspec, K.sep_can, ids);
     DTLArgs a{};
@@ -147,6 +149,19 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     a.tok_sep = K.tok_sep; a.tok_non = K.tok_non; a.tok_bad = K.tok_bad;
     a.Me = B * (L + P);
     a.skip_x32 = (PREC == 1 && D >= 256 && c->opt.dtl_ffn == 2) ? 1 : 0;       // every layer then runs dtl_ffn_kernel<.., OUTPROJ>, which carries the stream in Xh
+    if constexpr (D >= 256) {
+        // streamed-weight embed kernel in the layer kernels' arithmetic (x3: split-fp16 products; the generic GEMM would run exact f32)
+        typedef DTLEmbedGeom<PREC, D> EG;
+        DTLEmbedArgs e{};
+        e.mem_feat = K.mem_feat; e.can_feat = K.can_feat; e.L = L; e.P = P; e.T = T; e.E = E; e.can_pos = K.can_pos; e.M = (int)M; e.Me = a.Me;
+        e.w = K.w_embed; e.bias = K.b_embed; e.ids = ids; e.lut_xy = K.lut_xy; e.lut_sz = K.lut_sz; e.lut_t = K.lut_t; e.lut_c = K.lut_c;
+        e.tok_sep = K.tok_sep; e.tok_non = K.tok_non; e.tok_bad = K.tok_bad; e.X = X; e.Xh = Xh; e.skip_x32 = a.skip_x32; e.xerr = K.xerr;
+        auto kern = dtl_embed_kernel<PREC, D>;
+        { int rc = ensure_lds(c, (const void*)kern, EG::LDS); if (rc) return rc; }
+        const int nbx = (e.Me + EG::BM - 1) / EG::BM + (e.M - e.Me + EG::BM - 1) / EG::BM;
+        TimedLaunch tl(c, s);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nbx), dim3(512), EG::LDS, s, e);
+    } else
     { int rc = dtl_gemm<GP, D, DTL_EPI_EMBED>(c, s, a, 1); if (rc) return rc; }
     for (int l = 0; l < K.nlayers; ++l) {
         const DTLayerW& W = K.layer[l];
@@ -178,7 +193,9 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
             f.Xop = Xop; f.Oop = O; f.X = X; f.Xh = Xh; f.w_out = W.w_out; f.w1 = W.w1; f.w2 = W.w2; f.b_out = W.b_out; f.g1 = W.g1; f.be1 = W.be1;
             f.b1 = W.b1; f.b2 = W.b2; f.gamma = W.g2; f.beta = W.be2; f.M = (int)M; f.FF = FF; f.act = K.act;
             f.xerr = K.xerr;
-            f.write_x32 = l == K.nlayers - 1;            // (f16 flavour: the float32 copy of the residual stream only where the decoder / `hidden` read it)
+            const bool last = l == K.nlayers - 1;
+            if (last && ffn_mode == 2) { f.dec_g = K.dec_g; f.dec_w = K.dec_w; f.dec_cb = K.dec_cb; f.dec_logit = rowlogit; dec_fused = true; }
+            f.write_x32 = last && K.hidden != nullptr;   // (f16 flavour: the float32 copy of the residual stream only where `hidden` reads it - the decoder runs in this kernel)
             constexpr int DK = D >= 256 ? D : 256;
             constexpr int BMF = DTLFfnGeom<PREC, DK>::BM;
             constexpr size_t flds = DTLFfnGeom<PREC, DK>::LDS;
@@ -226,8 +243,9 @@ static int dt_forward_tiled(busca_ctx* c, const DTParams& K, hipStream_t s) {
     }
     if (K.hidden) HIP_TRY(c, hipMemcpyAsync(K.hidden, X, M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     { TimedLaunch tl(c, s);
-      hipLaunchKernelGGL((dtl_decoder_kernel<D>), dim3(B), dim3(256), 0, s, (const float*)X, T, L, P, K.can_pos, K.nspec, K.dec_g, K.dec_b, K.dec_w, K.dec_bias,
-                         K.logits, K.probs, K.argmax); }
+      if (dec_fused) hipLaunchKernelGGL((dtl_decoder_rows_kernel<0>), dim3((B + 3) / 4), dim3(256), 0, s, (const float*)rowlogit, B, T, L, P, K.can_pos, K.nspec, K.logits, K.probs, K.argmax);
+      else hipLaunchKernelGGL((dtl_decoder_kernel<D>), dim3(B), dim3(256), 0, s, (const float*)X, T, L, P, K.can_pos, K.nspec, K.dec_g, K.dec_b, K.dec_w, K.dec_bias,
+                              K.logits, K.probs, K.argmax); }
     HIP_TRY(c, hipGetLastError());
     return BUSCA_OK;
 }

@@ -28,6 +28,7 @@ struct DTParams {
     const float *tok_sep, *tok_non, *tok_bad;
     DTLayerW layer[DT_MAX_LAYERS];
     const float *dec_g, *dec_b, *dec_w; float dec_bias;
+    float dec_cb;             // sum_f dec_b[f] dec_w[f] + dec_bias (host, float64 accumulation): the row-independent part of the decoder's Linear(LayerNorm(x)) (layer-wise path)
     const _Float16 *lut_xy, *lut_sz, *lut_t; int lut_c;
     const float *mem_feat, *can_feat, *mem_ltrb, *can_ltrb;
     float* logits; float* probs; int* argmax; float* hidden; float* att;
