@@ -69,8 +69,8 @@ class StepBatcher:
             dev = feats[0][0].device
             mem_feat = torch.cat([f[0] for f in feats], 0)
             can_feat = torch.cat([f[1] for f in feats], 0)
-            mem_ltrb = torch.cat([torch.from_numpy(t._job["mem_ltrb"]) for t in ts], 0).to(dev)
-            can_ltrb = torch.cat([torch.from_numpy(t._job["can_ltrb"]) for t in ts], 0).to(dev)
+            mem_ltrb = torch.cat([torch.from_numpy(t._job["mem_ltrb"]) for t in ts], 0).pin_memory().to(dev, non_blocking=True)
+            can_ltrb = torch.cat([torch.from_numpy(t._job["can_ltrb"]) for t in ts], 0).pin_memory().to(dev, non_blocking=True)
             prev = m._ctx.get_option("dt_ntrk")                   # a pin (BUSCA_DT_NTRK / an earlier set_option) outranks the batcher's choice and survives it
             m._ctx.set_option("dt_ntrk", prev if prev != 0 else ntrk)
             try:

@@ -67,6 +67,8 @@ class DecisionTransformerHIP:
     def _f32(t, dev):
         if not torch.is_tensor(t):
             t = torch.as_tensor(np.asarray(t))
+        if t.device.type == "cpu":      # host boxes / features: pinned staging + asynchronous copy (a pageable `.to` parks the host behind everything queued on the stream)
+            t = t.to(torch.float32).contiguous().pin_memory().to(dev, non_blocking=True)
         return t.to(device=dev, dtype=torch.float32).contiguous()
 
     def forward(self, mem_feat, can_feat, mem_ltrb, can_ltrb, want_hidden=False, want_att=False, stream=None):

@@ -29,6 +29,16 @@ def _f64(x, ctx):
     return x.to(device=_dev(ctx), dtype=torch.float64).contiguous().view(-1, 4) if x.numel() else torch.zeros(0, 4, dtype=torch.float64, device=_dev(ctx))
 
 
+def h2d_async(arr, dev):
+    """Small host array -> device tensor without the host waiting for the stream: pinned staging (torch's caching host allocator keeps the block until the copy has
+    run) + an asynchronous copy.  A plain `.to(dev)` of a pageable array is a SYNCHRONOUS copy on the current stream: enqueued behind a ReID pass it parks the host
+    until the pass is done, and everything the host still has to enqueue (index gathers, the Decision-Transformer launch) then starts late."""
+    t = arr if torch.is_tensor(arr) else torch.from_numpy(np.ascontiguousarray(arr))
+    if t.device.type != "cpu":
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 def pairwise(ctx, a, b, mode, scores_b=None):
     """[nA,4],[nB,4] float64 ltrb -> float64 [nA,nB] on the GPU (mode: _lib.PAIR_*)."""
     a, b = _f64(a, ctx), _f64(b, ctx)

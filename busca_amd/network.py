@@ -452,9 +452,9 @@ class BUSCA:
     def _assoc_slots(self, job, mem_feat, can_feat):
         dev = mem_feat.device                  # features of the distinct crops -> the [B, L] / [B, P] slots they stand for
         if len(job["mem_inv"]) != mem_feat.shape[0] or (job["mem_inv"] != np.arange(len(job["mem_inv"]))).any():
-            mem_feat = mem_feat[torch.from_numpy(job["mem_inv"]).to(dev)]
+            mem_feat = mem_feat[geometry.h2d_async(job["mem_inv"], dev)]
         if len(job["can_inv"]) != can_feat.shape[0] or (job["can_inv"] != np.arange(len(job["can_inv"]))).any():
-            can_feat = can_feat[torch.from_numpy(job["can_inv"]).to(dev)]
+            can_feat = can_feat[geometry.h2d_async(job["can_inv"], dev)]
         return mem_feat.view(job["B"], job["L"], -1), can_feat.view(job["B"], job["P"], -1)
 
     def _assoc_exact_reid(self, job):
@@ -558,7 +558,7 @@ class BUSCA:
         self.last_unique = (len(uniq), len(flat))
         zn = None
         if zero_is_normalised and (uniq == 0).any():
-            zn = torch.from_numpy((uniq == 0).astype(np.uint8)).to(dev)
+            zn = geometry.h2d_async((uniq == 0).astype(np.uint8), dev)
         wts = counts.astype(np.float32) if (counts > 1).any() else None
         return out, zn, wts, inverse
 

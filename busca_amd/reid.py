@@ -87,8 +87,10 @@ class ReIDEncoderHIP:
             w = np.ascontiguousarray(weights, dtype=np.float32)
             assert w.shape == (n,) and (w >= 1).all()
             wsum = float(w.astype(np.float64).sum())
-            wd = torch.from_numpy(w).to(dev)
-            if stream is not None:
-                wd.record_stream(torch.cuda.ExternalStream(stream, device=dev))
+            if stream is not None:      # the copy must be ordered on the stream the pass runs on
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                    wd = torch.from_numpy(w).pin_memory().to(dev, non_blocking=True)
+            else:
+                wd = torch.from_numpy(w).pin_memory().to(dev, non_blocking=True)
         self.ctx.check(self.ctx.lib.busca_reid_forward_w(self.ctx.h, crops_u8.data_ptr(), n, zn, _ptr(wd), wsum, feats.data_ptr(), s))
         return feats

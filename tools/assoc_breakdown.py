@@ -10,7 +10,7 @@ lost = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 objs = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 args = types.SimpleNamespace(num_layer=4, nhead=4, dim_embedding=512, trans_dim=512, ff_size=1024, activation="gelu", dropout_p=0.1,
                              input_flavour="MEM-SEP-CAN-BAD", output_flavour="CAN", encode_separator_as_reference=True,
-                             encode_special_tokens=False, reid_weights_file="no", device=torch.device("cuda:0"), precision="f16", seed=7)
+                             encode_special_tokens=False, reid_weights_file="no", device=torch.device("cuda:0"), precision=os.environ.get("AB_PREC", "x3"), reid_precision=os.environ.get("AB_REID", "x3"), seed=7)
 m = BUSCA(args).to(torch.device("cuda:0")).eval()
 sc = SimScene(m, n_objects=objs)
 sc.warm_up(12)
