@@ -127,6 +127,37 @@ def test_x3_beyond_the_one_kernel_shapes(ctx, shape):
     assert np.abs(outs["x3"]["logits"]).max() > 0 and np.ptp(outs["x3"]["logits"]) > 1e-3
 
 
+@pytest.mark.parametrize("flavour,sep_ref", [("MEM-CAN-SEP", False), ("MEM-SEP-CAN", True), ("MEM-CAN-SEP-BAD", True), ("MEM-SEP-CAN-BAD", False)])
+@pytest.mark.parametrize("prec", ["f32", "x3", "f16"])
+@pytest.mark.parametrize("d", [256, 512])
+def test_tiled_token_layouts_at_the_fused_layer_kernels_widths(ctx, force_tiled, flavour, sep_ref, prec, d):
+    """The layer-wise path at d >= 256 has kernels of its own for the embed pass (compacted feature rows, special rows filled by the workgroups behind them) and for the
+    decoder (per-row logits from the last layer kernel + dtl_decoder_rows_kernel): every token layout of network.py:103-165 - candidate before / after its separator,
+    with / without the BAD token, separators encoded as the reference box or as their candidate's - against the oracle, hidden states of every token included (the
+    golden fixtures of these layouts are d = 64, which runs the generic kernels)."""
+    from busca_amd.dt import DecisionTransformerHIP
+    from oracle import dt as odt
+    tol = TOL32 if prec in ("f32", "x3") else TOL
+    B, L, P, seed = 7, 11, 9, 400 + d
+    sd = synth.dt_state_dict(seed, d=d, ff=2 * d, flavour=flavour)
+    inp = synth.dt_inputs(seed, B, L, P, sentinel_every=3)
+    m = DecisionTransformerHIP(ctx, sd, activation="relu", precision=prec, input_flavour=flavour, encode_separator_as_reference=sep_ref)
+    out = m.forward(inp["mem_feat"], inp["can_feat"], inp["mem_boxes"], inp["can_boxes"], want_hidden=True)
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    ref = odt.dt_forward(sd, odt.DTConfig(d=d, ff=2 * d, flavour=flavour, encode_sep_as_ref=sep_ref), **inp, return_all=True)
+    n = P + (2 if "BAD" in flavour else 1)
+    assert out["logits"].shape == (B, n) and out["hidden"].shape == (B, L + 2 * n, d)
+    assert np.abs(out["logits"] - ref["logits"].numpy()).max() <= tol["logit"]
+    assert np.abs(out["probs"] - ref["probs"].numpy()).max() <= tol["prob"]
+    assert np.abs(out["hidden"] - ref["hidden"].numpy()).max() <= tol["hidden"]
+    rp = ref["probs"].numpy()
+    srt = np.sort(rp, axis=-1)
+    clear = (srt[:, -1] - srt[:, -2]) > tol["margin"]
+    assert (out["argmax"][clear] == ref["argmax"].numpy()[clear]).all() and (out["argmax"] == out["probs"].argmax(-1)).all()
+    assert ctx.get_option("dt_status") == 0
+
+
 def test_unsupported_shape_is_refused_loudly(ctx):
     """More than 144 tokens per track is beyond every path: a BuscaError, never a silent fallback."""
     from busca_amd import _lib
